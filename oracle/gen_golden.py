@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz|*.pt by running the REFERENCE's own code in the build container.
+
+TEST INFRASTRUCTURE ONLY.  Run once, here, where /root/reference exists:
+
+    python oracle/gen_golden.py            # writes tests/golden/
+
+What is imported from the reference:
+  * src/mapping.py  -> SemanticMapping.project_pcd / update_map (:357-444), called unbound on a
+    SimpleNamespace.  ROS / cv2 / hickle / yacs / cv_bridge and the unparsable test module are
+    replaced by empty stub modules (none of them is touched by the two functions), except
+    get_transform_from_pose, which needs ROS tf: it is patched to oracle.mapping_oracle's
+    restatement (so the world-frame fixture pins everything except that 4x4 -- "parity unpinned").
+  * src/camera.py   -> camera_setup_1 / camera_setup_6 (real import, numpy only).
+  * src/network/core/nn/modules + deeplab_v3_plus/models/{aspp,decoder}.py -> real torch modules,
+    CPU forward at small sizes with seeded weights and randomised BN statistics.
+The backbone (torchvision) cannot be imported here; it has no fixture (parity unpinned).
+
+The fixtures hold inputs and expected outputs only -- no reference source text.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+from oracle import mapping_oracle as mo  # noqa: E402
+from vision_semantic_segmentation_amd import synthetic as syn  # noqa: E402
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference_mapping():
+    class _Any(object):
+        def __init__(self, *a, **k):
+            pass
+
+    for name in ["cv2", "rospy", "hickle", "tf_conversions", "yacs"]:
+        _stub(name)
+    _stub("cv_bridge", CvBridge=_Any, CvBridgeError=Exception)
+    _stub("geometry_msgs")
+    _stub("geometry_msgs.msg", PoseStamped=_Any, Pose=_Any, TransformStamped=_Any)
+    _stub("sensor_msgs", point_cloud2=types.ModuleType("point_cloud2"))
+    _stub("sensor_msgs.msg", Image=_Any, PointCloud2=_Any, PointField=_Any)
+    _stub("sensor_msgs.point_cloud2")
+    _stub("std_msgs")
+    _stub("std_msgs.msg", Header=_Any)
+    _stub("tf", TransformListener=_Any, TransformerROS=_Any, TransformBroadcaster=_Any,
+          LookupException=Exception, ConnectivityException=Exception, ExtrapolationException=Exception)
+    _stub("tf.transformations", euler_matrix=None, quaternion_matrix=None, euler_from_quaternion=None)
+    _stub("yacs.config", CfgNode=dict)
+    sys.modules["rospy"].Publisher = _Any
+    sys.path.insert(0, os.path.join(REF, "src"))
+    sys.path.insert(0, REF)
+    _stub("src.config.base_cfg", get_cfg_defaults=lambda: None)
+    _stub("test.test_semantic_mapping", Test=_Any)      # real file is a SyntaxError
+    import src.mapping as ref_mapping
+    import src.camera as ref_camera
+    return ref_mapping, ref_camera
+
+
+class _Cam(object):
+    def __init__(self, P):
+        self.P = P
+
+
+def sparse_map(m):
+    idx = np.argwhere(np.any(m != 0, axis=2)).astype(np.int32)
+    return idx, m[idx[:, 0], idx[:, 1], :]
+
+
+def gen_mapping(ref_mapping, ref_camera):
+    SM = ref_mapping.SemanticMapping
+    cam1 = ref_camera.camera_setup_1()
+    cam6 = ref_camera.camera_setup_6()
+    # the oracle's camera restatement must equal the reference's
+    for cid, cam in ((1, cam1), (6, cam6)):
+        c = mo.camera_matrices(cid)
+        assert np.array_equal(c["P"], cam.P) and np.array_equal(c["T"], cam.T)
+    np.savez_compressed(os.path.join(OUT, "camera.npz"), P1=cam1.P, P6=cam6.P, T1=cam1.T, T6=cam6.T,
+                        K1=cam1.K, K6=cam6.K, R1=cam1.R, t1=cam1.t, R6=cam6.R, t6=cam6.t)
+
+    ref_mapping.get_transform_from_pose = lambda pose: mo.transform_from_pose(pose)
+    T_v2b = mo.velodyne_to_baselink()
+
+    cases = [
+        # name, seed, n, (H, W), cam, frame, res, half-extent, CM, intensity
+        dict(name="A_velodyne_identity", seed=0, n=10000, hw=(480, 640), cam=1, frame="velodyne",
+             res=0.2, half=100.0, cm="eye", intensity=True, cam_scale=(640 / 1920.0, 480 / 1440.0)),
+        dict(name="C_velodyne_logcm", seed=1, n=30000, hw=(1080, 1920), cam=1, frame="velodyne",
+             res=0.2, half=200.0, cm="log", intensity=True, cam_scale=None),
+        dict(name="W_world_pose_cam6", seed=2, n=12000, hw=(1080, 1920), cam=6, frame="map",
+             res=0.1, half=60.0, cm="log", intensity=False, cam_scale=None),
+        dict(name="E_dense_dupes", seed=3, n=40000, hw=(1080, 1920), cam=1, frame="velodyne",
+             res=1.0, half=50.0, cm="log", intensity=True, cam_scale=None),
+    ]
+    for c in cases:
+        rng = np.random.default_rng(c["seed"])
+        H, W = c["hw"]
+        cam = cam1 if c["cam"] == 1 else cam6
+        K = cam.K.copy()
+        if c["cam_scale"]:
+            K[0] *= c["cam_scale"][0]
+            K[1] *= c["cam_scale"][1]
+        P = np.matmul(K, np.concatenate([cam.R, cam.t], axis=1))
+        pts = syn.make_cloud(rng, c["n"], K, cam.R, cam.t, W, H)
+        # adversarial extras (Q3/Q4/Q5): exact duplicates, intensity thresholds, sub-pixel-negative columns
+        pts[:, 1:200:2] = pts[:, 0:199:2]
+        pts[3, 200:208] = [1.9, 2.0, 14.0, 14.1, np.nan, -1.0, 1e9, 0.0]
+        # a point that projects into (-1, 0) px horizontally: take u = -0.5
+        xc = np.linalg.inv(K) @ np.array([[-0.5], [H / 2.0], [1.0]]) * 10.0
+        pts[0:3, 208:209] = cam.R.T @ (xc - cam.t)
+        xc = np.linalg.inv(K) @ np.array([[W / 2.0], [-0.25], [1.0]]) * 10.0
+        pts[0:3, 209:210] = cam.R.T @ (xc - cam.t)
+        pts[0:3, 210] = [3.0e9, 1.0, 1.0]
+        # camera-plane point: z_cam == 0 -> division by zero
+        pts[0:3, 211:212] = cam.R.T @ (np.array([[1.0], [2.0], [0.0]]) - cam.t)
+
+        pose7 = None
+        pcd = pts
+        if c["frame"] != "velodyne":
+            # put the cloud into a world frame through a non-trivial pose (Q6)
+            q = np.array([0.02, -0.03, 0.6, 0.79])
+            q = q / np.linalg.norm(q)
+            pose7 = np.array([-1369.0496826171875 + 1400.0, -562.84814453125 + 600.0, 1.5, q[0], q[1], q[2], q[3]])
+            T = np.matmul(mo.transform_from_pose(pose7), T_v2b)
+            pcd = pts.copy()
+            with np.errstate(all="ignore"):
+                pcd[0:3] = np.matmul(T, mo.homogenize(pts[0:3]))[0:3]
+
+        label_map = syn.make_label_map(rng, H, W)
+        image = syn.colorize(label_map)
+        # Q2: pixels whose (R,G) match a map class but whose B does not, and the reverse
+        image[5:40, 5:200] = [128, 64, 7]
+        image[50:90, 300:500] = [128, 65, 128]
+        image[100:140, 0:300] = [255, 255, 0]
+
+        if c["frame"] == "velodyne":
+            centre = (mo.PCD_ORIGIN_OFFSET[0], mo.PCD_ORIGIN_OFFSET[1])
+        else:
+            centre = (pose7[0] + mo.PCD_ORIGIN_OFFSET[0], pose7[1] + mo.PCD_ORIGIN_OFFSET[1])
+        boundary = syn.centred_boundary(centre, c["half"])
+        mh, mw = mo.map_dims(boundary, c["res"])
+        cm = np.eye(5) if c["cm"] == "eye" else syn.log_confusion(5)
+
+        ns = types.SimpleNamespace(
+            pcd_range_max=100.0, T_velodyne_to_basklink=T_v2b, map_boundary=boundary, resolution=c["res"],
+            map_height=mh, map_width=mw, label_names=list(mo.LABELS_NAMES),
+            label_colors=np.array(mo.LABEL_COLORS), confusion_matrix=cm, use_pcd_intensity=c["intensity"])
+
+        with np.errstate(all="ignore"):
+            masked_pcd, label = SM.project_pcd(ns, pcd, c["frame"], image, pose7, _Cam(P))
+            grid = np.zeros((mh, mw, 5))
+            grid = SM.update_map(ns, grid, masked_pcd, label)
+            # second frame on top of the first: exercises accumulation (a9)
+            pcd2 = pcd.copy()
+            pcd2[0:2] += 0.37
+            masked2, label2 = SM.project_pcd(ns, pcd2, c["frame"], image, pose7, _Cam(P))
+            grid2 = SM.update_map(ns, grid.copy(), masked2, label2)
+        idx1, val1 = sparse_map(grid)
+        idx2, val2 = sparse_map(grid2)
+        print("%-22s N=%d M=%d cells=%d / %d" % (c["name"], pcd.shape[1], masked_pcd.shape[1], len(idx1), len(idx2)))
+        assert masked_pcd.shape[1] > 0.5 * c["n"] and len(idx1) > 100
+        np.savez_compressed(
+            os.path.join(OUT, "mapping_%s.npz" % c["name"]),
+            pcd=pcd, frame=np.array(c["frame"]), image=image, pose7=np.zeros(0) if pose7 is None else pose7, P=P,
+            T_v2b=T_v2b, boundary=np.array(boundary), resolution=np.array(c["res"]), cm=cm,
+            use_intensity=np.array(c["intensity"]), range_max=np.array(100.0),
+            masked_pcd=masked_pcd, label=label, map_idx=idx1, map_val=val1,
+            masked_pcd2=masked2, label2=label2, map2_idx=idx2, map2_val=val2)
+
+
+def gen_network():
+    import torch
+    sys.path.insert(0, os.path.join(REF, "src", "network"))
+    from core.nn.modules import Conv2d, DepthwiseSeparableConv2d
+    from deeplab_v3_plus.models.aspp import AtrousSpatialPyramidPoolingModule
+    from deeplab_v3_plus.models.decoder import Decoder
+
+    def randomise_bn(module, gen):
+        for m in module.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=gen) * 0.2)
+                m.running_var.copy_(torch.rand(m.num_features, generator=gen) * 1.5 + 0.25)
+                m.weight.data.copy_(torch.rand(m.num_features, generator=gen) + 0.5)
+                m.bias.data.copy_(torch.randn(m.num_features, generator=gen) * 0.1)
+
+    torch.manual_seed(1234)
+    gen = torch.Generator().manual_seed(99)
+    with torch.no_grad():
+        aspp = AtrousSpatialPyramidPoolingModule(in_channels=32, out_channels=24, atrous_channels=(16, 16, 16, 16),
+                                                 atrous_kernel_size=(1, 3, 3, 3), atrous_dilation=(1, 12, 24, 36))
+        randomise_bn(aspp, gen)
+        aspp.eval()
+        x = torch.randn(1, 32, 45, 50, generator=gen)
+        y = aspp(x)
+        torch.save({"state": aspp.state_dict(), "x": x, "y": y}, os.path.join(OUT, "net_aspp.pt"))
+        print("aspp", tuple(x.shape), "->", tuple(y.shape))
+
+        dec = Decoder(in_channels=24, out_channels=19, low_level_in_channels=16, low_level_out_channels=12,
+                      refine_channels=(20, 20), refine_kernel_size=(3, 3))
+        randomise_bn(dec, gen)
+        dec.eval()
+        f = torch.randn(1, 24, 20, 25, generator=gen)
+        low = torch.randn(1, 16, 40, 50, generator=gen)
+        y = dec(f, low)
+        torch.save({"state": dec.state_dict(), "feature": f, "low": low, "y": y}, os.path.join(OUT, "net_decoder.pt"))
+        print("decoder", tuple(f.shape), tuple(low.shape), "->", tuple(y.shape))
+
+        c = Conv2d(8, 12, 3, bn=True, relu=True, stride=2, padding=2, dilation=2, groups=4)
+        randomise_bn(c, gen)
+        c.eval()
+        d = DepthwiseSeparableConv2d(8, 6, 3, dilation=3, padding=3, depthwise_bn=True, pointwise_bn=True,
+                                     depthwise_relu=True, pointwise_relu=False)
+        randomise_bn(d, gen)
+        d.eval()
+        x = torch.randn(1, 8, 17, 23, generator=gen)
+        torch.save({"conv_state": c.state_dict(), "dw_state": d.state_dict(), "x": x, "y_conv": c(x), "y_dw": d(x)},
+                   os.path.join(OUT, "net_blocks.pt"))
+        print("blocks ok")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    ref_mapping, ref_camera = import_reference_mapping()
+    gen_mapping(ref_mapping, ref_camera)
+    gen_network()
