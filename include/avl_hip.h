@@ -1,0 +1,139 @@
+/*
+ * avl_hip.h -- C ABI of libavl_hip.so: the MI355X (gfx950) implementation of the per-frame hot
+ * path of AutonomousVehicleLaboratory/vision_semantic_segmentation.
+ *
+ * The reference has no FFI layer (it is pure Python); each entry point below names the reference
+ * function whose arithmetic it replaces (file:line under the reference root).  The Python shim in
+ * vision_semantic_segmentation_amd/ binds these with ctypes and keeps the reference's class and
+ * method names; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is
+ *     asynchronous on it, nothing synchronises, nothing allocates;
+ *   - the caller owns every buffer, including scratch; the library keeps no pointer after return
+ *     (plan objects excepted: they keep the op list they were given);
+ *   - return value: 0 on success, a negative AVL_E_* code otherwise; avl_last_error() then holds
+ *     a message for the calling thread.  Nothing throws.
+ */
+#ifndef AVL_HIP_H
+#define AVL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVL_OK 0
+#define AVL_E_ARG (-1)      /* bad argument (null pointer, non-positive size, bad enum) */
+#define AVL_E_HIP (-2)      /* a HIP runtime call failed                                */
+#define AVL_E_UNSUPPORTED (-3)
+
+/* point / grid element types */
+#define AVL_F32 0
+#define AVL_F64 1
+#define AVL_BF16 2
+
+/* vote-mask layout (one uint32 per grid cell, 0 between frames):
+ *   bit i        (i < 16) : some point of map class i fell into the cell this frame
+ *   bit 16 + i            : ... and one of them qualified for the intensity bonus (+2 on channel i) */
+#define AVL_MAX_MAP_CLASSES 16
+
+/* ---- library ---------------------------------------------------------------------------- */
+const char* avl_version(void);
+/* copies the calling thread's last error message into buf (NUL terminated); returns its length */
+int avl_last_error(char* buf, int len);
+
+/* ---- a7: SemanticMapping.project_pcd (src/mapping.py:357-389) ---------------------------- */
+
+/* Projection only -- lines :367-383.  Point k's component c (0=x,1=y,2=z,3=intensity) is read at
+ * pts + k*point_stride + c*comp_stride (bytes) as `dtype` and widened to double.
+ * T (row-major 4x4) = T_origin_to_velodyne of :369, or NULL for pcd_frame_id == "velodyne" (:373).
+ * P (row-major 3x4) = Camera.P (src/camera.py:28).
+ * out_ixy int32[2][n] = dehomogenize(P Xv).astype(int32) (:375, INT_MIN for nan/inf/overflow),
+ * out_mask uint8[n]   = the mask of :378-383.  Either may be NULL. */
+int avl_project_points(const void* pts, int n, int dtype, int64_t point_stride, int64_t comp_stride,
+                       const double* P_host, const double* T_host, double range_max,
+                       int img_w, int img_h, int32_t* out_ixy, uint8_t* out_mask, void* stream);
+
+/* bytes of scratch avl_project_pcd needs for n points */
+int64_t avl_project_pcd_scratch_bytes(int n);
+
+/* Whole project_pcd: projection, mask, ORDER-PRESERVING compaction (:385) and label gather (:387).
+ * image uint8[img_h][img_w][3].  Outputs have capacity n and leading dimension out_ld (>= n):
+ * out_pcd double[4][out_ld] (the ORIGINAL-frame columns of pcd that passed, Q6),
+ * out_label uint8[3][out_ld], out_count int32[1] = M. */
+int avl_project_pcd(const void* pts, int n, int dtype, int64_t point_stride, int64_t comp_stride,
+                    const double* P_host, const double* T_host, double range_max,
+                    const uint8_t* image, int img_w, int img_h,
+                    double* out_pcd, uint8_t* out_label, int64_t out_ld, int32_t* out_count,
+                    void* scratch, void* stream);
+
+/* ---- a8: SemanticMapping.update_map (src/mapping.py:391-444) ------------------------------ */
+
+typedef struct avl_grid {
+    void* map;            /* [Hm][Wm][C] of map_dtype (AVL_F64 = the reference's type, or AVL_F32) */
+    int map_dtype;
+    int Hm, Wm, C;        /* Hm indexes x, Wm indexes y (src/mapping.py:115-116); C <= 16        */
+    double off_x, off_y;  /* pcd_origin_offset (:404)                                             */
+    double b00, b10;      /* map_boundary[0][0], map_boundary[1][0] (:408)                        */
+    double resolution;    /* (:409)                                                               */
+    uint32_t* cell_mask;  /* scratch uint32[Hm*Wm]; all zero on entry, all zero again on return   */
+    int32_t* touched;     /* scratch int32[touched_cap]: cells first touched this frame           */
+    int32_t touched_cap;  /* >= min(n points, Hm*Wm)                                              */
+    int32_t* counter;     /* scratch int32[4] (16-byte block of its own); zeroed by the call      */
+} avl_grid;
+
+/* update_map for points that already carry an RGB label (the reference's own signature).
+ * pcd double[4][ld] (rows x,y,z,intensity), label uint8[3][ld]; the number of points is m_host,
+ * or *m_dev when m_dev != NULL (then m_host is the capacity the launch is sized for).
+ * label_colors_host uint8[C][3]; only R and G are compared (Q2).
+ * cm_host double[C][C]: column i is added to every cell holding a class-i point, once (Q1).
+ * bonus_classes: bit i set => class i gets +2 on channel i when a point with intensity < 2 or > 14
+ * is present (:431-437); 0 when MAPPING.PCD.USE_INTENSITY is false. */
+int avl_update_map(const avl_grid* g, const double* pcd, const uint8_t* label, int64_t ld,
+                   int m_host, const int32_t* m_dev,
+                   const uint8_t* label_colors_host, const double* cm_host, uint32_t bonus_classes,
+                   void* stream);
+
+/* The two stages of avl_update_map, separately.
+ * avl_vote_points: :403-437 up to the `+=` -- every point ORs its vote into cell_mask[cell]; the
+ * cells it turned non-zero are listed in g->touched[0 .. g->counter[0]).  (g->map is not touched.)
+ * avl_grid_apply: the buffered `+=` (:424,:437) for the listed cells, then clears their masks.
+ * rows == NULL: applied to g->map.  rows != NULL: row k of rows ([count][C], rows_dtype) stands for
+ * cell touched[k] -- for callers whose grid lives in host memory and who move only touched rows. */
+int avl_vote_points(const avl_grid* g, const double* pcd, const uint8_t* label, int64_t ld,
+                    int m_host, const int32_t* m_dev, const uint8_t* label_colors_host,
+                    uint32_t bonus_classes, void* stream);
+int avl_grid_apply(const avl_grid* g, const double* cm_host, void* rows, int rows_dtype, void* stream);
+
+/* ---- a9: one fused frame of SemanticMapping.mapping (src/mapping.py:314-319) --------------- */
+
+/* semantic source kinds */
+#define AVL_SRC_RGB 0       /* uint8[src_h][src_w][3] colour image, matched on R,G (the ROS topic)     */
+#define AVL_SRC_CLASSMAP 1  /* uint8[src_h][src_w] network class ids + lut: the un-colourised argmax   */
+
+/* project_pcd + update_map without materialising the intermediate point list: every point is
+ * projected, its label fetched, its grid cell computed from the ORIGINAL coordinates, and its vote
+ * OR-ed into cell_mask; then the touched cells are updated once.  For AVL_SRC_CLASSMAP the source is
+ * sampled as cv2.resize(..., (img_w,img_h), INTER_NEAREST) would have enlarged it
+ * (vision_semantic_segmentation_node.py:109-110) and lut_host uint32[256] maps a network class to its
+ * vote bits (= R,G match of its palette colour against LABEL_COLORS). For AVL_SRC_RGB src_w/src_h must
+ * equal img_w/img_h and label_colors_host is used instead of the lut. */
+int avl_fused_frame(const avl_grid* g, const void* pts, int n, int dtype, int64_t point_stride,
+                    int64_t comp_stride, const double* P_host, const double* T_host, double range_max,
+                    int src_kind, const uint8_t* src, int src_w, int src_h, int img_w, int img_h,
+                    const uint32_t* lut_host, const uint8_t* label_colors_host,
+                    const double* cm_host, uint32_t bonus_classes, void* stream);
+
+/* a6: colourised full-resolution semantic image from the small argmax map
+ * (vision_semantic_segmentation_node.py:102,109-116): nearest upscale + palette LUT.
+ * labels uint8[lh][lw]; palette_host uint8[256][3]; out uint8[out_h][out_w][3]. */
+int avl_colorize_labels(const uint8_t* labels, int lw, int lh, const uint8_t* palette_host,
+                        uint8_t* out, int out_w, int out_h, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVL_HIP_H */

@@ -147,7 +147,8 @@ def project_pcd(pcd, pcd_frame_id, image, pose7, P, range_max, T_velodyne_to_bas
     if pcd_frame_id != "velodyne":                                       # :367
         T_base_to_origin = transform_from_pose(pose7)                    # :368
         T_origin_to_velodyne = np.linalg.inv(np.matmul(T_base_to_origin, T_velodyne_to_baselink))  # :369
-        pcd_velodyne = np.matmul(T_origin_to_velodyne, homogenize(pcd[0:3, :]))                    # :371
+        with np.errstate(all="ignore"):
+            pcd_velodyne = np.matmul(T_origin_to_velodyne, homogenize(pcd[0:3, :]))                # :371
     else:
         pcd_velodyne = homogenize(pcd[0:3, :])                           # :373
 

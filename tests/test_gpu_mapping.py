@@ -1,0 +1,207 @@
+"""HIP mapping kernels (through the C ABI, via the reference-shaped SemanticMapping class) against
+the NumPy oracle and the reference-generated golden fixtures.  Integer results are compared
+bit-exactly; with a float64 grid the log-odds are compared bit-exactly too."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mapping_*.npz")))
+
+
+def make_sm(boundary, res, cm, use_intensity, device, grid_dtype="f64", range_max=100.0):
+    from vision_semantic_segmentation_amd import SemanticMapping, get_cfg_defaults
+    from vision_semantic_segmentation_amd.utils.logger import MyLogger
+    cfg = get_cfg_defaults()
+    cfg.MAPPING.BOUNDARY = boundary
+    cfg.MAPPING.RESOLUTION = res
+    cfg.MAPPING.PCD.USE_INTENSITY = bool(use_intensity)
+    cfg.MAPPING.PCD.RANGE_MAX = range_max
+    cfg.MAPPING.GRID_DTYPE = grid_dtype
+    sm = SemanticMapping(cfg, device=device, logger=MyLogger("test", quiet=True))
+    sm.confusion_matrix = np.array(cm)
+    return sm
+
+
+class _Cam(object):
+    def __init__(self, P):
+        self.P = P
+
+
+def dense(idx, val, shape):
+    m = np.zeros(shape)
+    m[idx[:, 0], idx[:, 1]] = val
+    return m
+
+
+def pose_of(g):
+    from vision_semantic_segmentation_amd.utils import Pose
+    return Pose.from_array(g["pose7"]) if g["pose7"].size else None
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[8:-4] for p in CASES])
+def test_project_pcd_and_update_map_match_golden(path, cuda_device):
+    g = np.load(path)
+    boundary, res = g["boundary"].tolist(), float(g["resolution"])
+    sm = make_sm(boundary, res, g["cm"], g["use_intensity"], cuda_device)
+    cam, pose, frame = _Cam(g["P"]), pose_of(g), str(g["frame"])
+    mp, lab = sm.project_pcd(g["pcd"], frame, g["image"], pose, cam)
+    assert mp.dtype == np.float64 and lab.dtype == np.uint8
+    assert np.array_equal(mp, g["masked_pcd"], equal_nan=True)       # order-preserving compaction, exact copies
+    assert np.array_equal(lab, g["label"])
+    # NumPy grid (the reference's calling convention): touched rows travel, arithmetic on the GPU
+    grid = np.zeros((sm.map_height, sm.map_width, sm.map_depth))
+    out = sm.update_map(grid, mp, lab)
+    assert out is grid
+    assert np.array_equal(grid, dense(g["map_idx"], g["map_val"], grid.shape))
+    out = sm.update_map(grid, g["masked_pcd2"], g["label2"])
+    assert np.array_equal(grid, dense(g["map2_idx"], g["map2_val"], grid.shape))
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[8:-4] for p in CASES])
+def test_fused_mapping_matches_golden(path, cuda_device):
+    """mapping() = fused project+vote+apply on the device grid; two frames accumulate."""
+    g = np.load(path)
+    boundary, res = g["boundary"].tolist(), float(g["resolution"])
+    sm = make_sm(boundary, res, g["cm"], g["use_intensity"], cuda_device)
+    cam, pose, frame = _Cam(g["P"]), pose_of(g), str(g["frame"])
+    sm.pcd, sm.pcd_frame_id = g["pcd"], frame
+    assert sm.map is None
+    sm.mapping(g["image"], pose, cam)
+    assert np.array_equal(sm.map, dense(g["map_idx"], g["map_val"], sm.map.shape))
+    pcd2 = g["pcd"].copy()
+    pcd2[0:2] += 0.37
+    sm.pcd = pcd2
+    sm.mapping(g["image"], pose, cam)
+    assert np.array_equal(sm.map, dense(g["map2_idx"], g["map2_val"], sm.map.shape))
+    # scratch contract: the vote masks are all zero again
+    assert int(sm.grid.cell_mask.abs().sum().item()) == 0
+
+
+def test_device_grid_f32_and_device_tensors(cuda_device):
+    """float32 grid + CUDA-tensor inputs: identity CM gives exact small integers in fp32."""
+    import torch
+    g = np.load(CASES[0])
+    boundary, res = g["boundary"].tolist(), float(g["resolution"])
+    sm = make_sm(boundary, res, g["cm"], g["use_intensity"], cuda_device, grid_dtype="f32")
+    mp = torch.from_numpy(g["masked_pcd"]).to(cuda_device)
+    lab = torch.from_numpy(g["label"]).to(cuda_device)
+    out = sm.update_map(sm.map_dev, mp, lab)
+    assert out.dtype == torch.float32 and out.is_cuda
+    ref = dense(g["map_idx"], g["map_val"], tuple(out.shape))
+    tol = 1e-3 * max(1.0, np.abs(ref).max())          # north_star: grid log-odds within 1e-3
+    assert np.max(np.abs(out.cpu().numpy().astype(np.float64) - ref)) <= tol
+
+
+def test_classmap_source_equals_colour_image_path(cuda_device):
+    """The fused class-map source (argmax map + LUT + nearest index map) must equal the reference
+    route: uint8 cast -> INTER_NEAREST upscale -> palette -> project_pcd -> update_map."""
+    import torch
+    from oracle import mapping_oracle as mo
+    from vision_semantic_segmentation_amd import synthetic as syn
+    from vision_semantic_segmentation_amd.camera import camera_setup_1
+    rng = np.random.default_rng(11)
+    H, W, lh, lw = 1080, 1920, 266, 476
+    cam = camera_setup_1()
+    pcd = syn.make_cloud(rng, 50000, cam.K, cam.R, cam.t, W, H)
+    small = syn.make_label_map(rng, lh, lw, tile=7)
+    boundary = syn.centred_boundary(mo.PCD_ORIGIN_OFFSET[:2], 100.0)
+    cm = syn.log_confusion(5)
+    sm = make_sm(boundary, 0.2, cm, True, cuda_device)
+    sm.frame_device(pcd, "velodyne", torch.from_numpy(small).to(cuda_device), None, cam, src_kind="classmap",
+                    image_size=(H, W))
+    image = mo.semantic_image_from_labels(small, H, W)
+    grid = np.zeros((sm.map_height, sm.map_width, 5))
+    cfg = dict(range_max=100.0, boundary=boundary, resolution=0.2, label_names=mo.LABELS_NAMES,
+               label_colors=mo.LABEL_COLORS, confusion_matrix=cm, use_pcd_intensity=True)
+    mo.mapping_frame(grid, pcd, "velodyne", image, None, cam.P, cfg)
+    assert np.count_nonzero(grid) > 1000
+    assert np.array_equal(sm.map, grid)
+    # and the colourised image the node would publish
+    from vision_semantic_segmentation_amd.vision_semantic_segmentation_node import colorize_labels_device
+    col = colorize_labels_device(torch.from_numpy(small).to(cuda_device), H, W).cpu().numpy()
+    assert np.array_equal(col, image)
+
+
+def test_projection_indices_bit_exact_float32_aos(cuda_device):
+    """avl_project_points on a float32 [N,4] cloud: int32 pixel indices and mask vs the oracle."""
+    import ctypes as C
+    import torch
+    from oracle import mapping_oracle as mo
+    from vision_semantic_segmentation_amd import _lib, synthetic as syn
+    from vision_semantic_segmentation_amd.camera import camera_setup_6
+    rng = np.random.default_rng(3)
+    cam = camera_setup_6()
+    H, W, n = 1440, 1920, 200000
+    pts32 = syn.make_cloud(rng, n, cam.K, cam.R, cam.t, W, H, dtype=np.float32)      # [4,N] f32
+    aos = torch.from_numpy(np.ascontiguousarray(pts32.T)).to(cuda_device)            # [N,4]
+    ixy = torch.empty((2, n), dtype=torch.int32, device=cuda_device)
+    mask = torch.empty(n, dtype=torch.uint8, device=cuda_device)
+    P = (C.c_double * 12)(*cam.P.ravel().tolist())
+    rc = _lib.lib().avl_project_points(C.c_void_p(aos.data_ptr()), n, _lib.AVL_F32, 16, 4, P, None, 100.0, W, H,
+                                       C.c_void_p(ixy.data_ptr()), C.c_void_p(mask.data_ptr()), None)
+    _lib.check(rc)
+    torch.cuda.synchronize()
+    image = np.zeros((H, W, 3), dtype=np.uint8)
+    with np.errstate(all="ignore"):
+        _, _, IXY, m = mo.project_pcd(pts32.astype(np.float64), "velodyne", image, None, cam.P, 100.0, return_debug=True)
+    assert np.array_equal(ixy.cpu().numpy(), IXY)
+    assert np.array_equal(mask.cpu().numpy().astype(bool), m)
+
+
+def test_edge_cases(cuda_device):
+    """Empty cloud, a cloud with no survivor, and argument errors reported through avl_last_error."""
+    g = np.load(CASES[0])
+    boundary, res = g["boundary"].tolist(), float(g["resolution"])
+    sm = make_sm(boundary, res, g["cm"], True, cuda_device)
+    cam = _Cam(g["P"])
+    mp, lab = sm.project_pcd(np.zeros((4, 0)), "velodyne", g["image"], None, cam)
+    assert mp.shape == (4, 0) and lab.shape == (3, 0)
+    behind = np.array([[-5.0, 0.0, 0.0, 1.0], [np.nan, 0, 0, 0]]).T
+    mp, lab = sm.project_pcd(behind, "velodyne", g["image"], None, cam)
+    assert mp.shape == (4, 0)
+    grid = np.zeros((sm.map_height, sm.map_width, 5))
+    assert sm.update_map(grid, mp, lab) is grid and not grid.any()
+    assert sm.project_pcd(None, "velodyne", g["image"], None, cam) is None
+    with pytest.raises(ValueError):
+        sm.project_pcd(np.zeros((3, 5)), "velodyne", g["image"], None, cam)
+
+
+def test_full_size_properties(cuda_device):
+    """BASELINE sizes (config C: 120k points, 2000x2000 grid @0.2 m; config E: 1M points, 4000x4000
+    @0.05 m) through properties that need no oracle at full size plus the oracle itself (it
+    finishes in < 1 s at these sizes): idempotence under point duplication (Q1), permutation
+    invariance, additivity of frames."""
+    import torch
+    from oracle import mapping_oracle as mo
+    from vision_semantic_segmentation_amd import synthetic as syn
+    from vision_semantic_segmentation_amd.camera import camera_setup_1
+    cam = camera_setup_1().scaled(1.0, 1080 / 1440.0)
+    for n, res, half in ((120000, 0.2, 200.0), (1000000, 0.05, 100.0)):
+        rng = np.random.default_rng(n)
+        H, W = 1080, 1920
+        pcd = syn.make_cloud(rng, n, cam.K, cam.R, cam.t, W, H)
+        image = syn.colorize(syn.make_label_map(rng, H, W))
+        boundary = syn.centred_boundary(mo.PCD_ORIGIN_OFFSET[:2], half)
+        cm = syn.log_confusion(5)
+        sm = make_sm(boundary, res, cm, True, cuda_device)
+        img_d = torch.from_numpy(image).to(cuda_device)
+        sm.frame_device(pcd, "velodyne", img_d, None, cam)
+        one = sm.map_dev.clone()
+        # oracle at full size
+        grid = np.zeros((sm.map_height, sm.map_width, 5))
+        cfg = dict(range_max=100.0, boundary=boundary, resolution=res, label_names=mo.LABELS_NAMES,
+                   label_colors=mo.LABEL_COLORS, confusion_matrix=cm, use_pcd_intensity=True)
+        mo.mapping_frame(grid, pcd, "velodyne", image, None, cam.P, cfg)
+        assert np.array_equal(one.cpu().numpy(), grid)
+        # duplicated + permuted cloud gives the same single-frame delta
+        sm.map = np.zeros_like(grid)
+        perm = rng.permutation(2 * n)
+        sm.frame_device(np.concatenate([pcd, pcd], axis=1)[:, perm], "velodyne", img_d, None, cam)
+        assert torch.equal(sm.map_dev, one)
+        # frames add: a second identical frame doubles every entry exactly (x + x is exact)
+        sm.frame_device(pcd, "velodyne", img_d, None, cam)
+        assert torch.equal(sm.map_dev, one * 2)

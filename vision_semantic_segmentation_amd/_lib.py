@@ -1,0 +1,95 @@
+"""ctypes binding of libavl_hip.so (include/avl_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavl_hip.so")
+
+AVL_F32, AVL_F64, AVL_BF16 = 0, 1, 2
+AVL_SRC_RGB, AVL_SRC_CLASSMAP = 0, 1
+AVL_MAX_MAP_CLASSES = 16
+
+_lib = None
+_lock = threading.Lock()
+
+
+class AvlGrid(C.Structure):
+    """struct avl_grid of include/avl_hip.h"""
+    _fields_ = [
+        ("map", C.c_void_p), ("map_dtype", C.c_int),
+        ("Hm", C.c_int), ("Wm", C.c_int), ("C", C.c_int),
+        ("off_x", C.c_double), ("off_y", C.c_double), ("b00", C.c_double), ("b10", C.c_double),
+        ("resolution", C.c_double),
+        ("cell_mask", C.c_void_p), ("touched", C.c_void_p), ("touched_cap", C.c_int32), ("counter", C.c_void_p),
+    ]
+
+
+_vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
+
+_SIGNATURES = {
+    "avl_version": (C.c_char_p, []),
+    "avl_last_error": (_i, [C.c_char_p, _i]),
+    "avl_project_points": (_i, [_vp, _i, _i, _i64, _i64, _vp, _vp, _d, _i, _i, _vp, _vp, _vp]),
+    "avl_project_pcd_scratch_bytes": (_i64, [_i]),
+    "avl_project_pcd": (_i, [_vp, _i, _i, _i64, _i64, _vp, _vp, _d, _vp, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "avl_update_map": (_i, [C.POINTER(AvlGrid), _vp, _vp, _i64, _i, _vp, _vp, _vp, C.c_uint32, _vp]),
+    "avl_vote_points": (_i, [C.POINTER(AvlGrid), _vp, _vp, _i64, _i, _vp, _vp, C.c_uint32, _vp]),
+    "avl_grid_apply": (_i, [C.POINTER(AvlGrid), _vp, _vp, _i, _vp]),
+    "avl_fused_frame": (_i, [C.POINTER(AvlGrid), _vp, _i, _i, _i64, _i64, _vp, _vp, _d, _i, _vp, _i, _i, _i, _i,
+                             _vp, _vp, _vp, C.c_uint32, _vp]),
+    "avl_colorize_labels": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp]),
+}
+
+
+def exported_symbols():
+    """Every symbol include/avl_hip.h declares (kept in step with the header by a test)."""
+    return sorted(_SIGNATURES) + sorted(_SEG_SIGNATURES)
+
+
+_SEG_SIGNATURES = {}
+
+
+def _register_seg(sigs):
+    _SEG_SIGNATURES.update(sigs)
+
+
+def lib():
+    """Load (once) and return the library; raise RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libavl_hip.so not found at %s -- build it with `make -C vision_semantic_segmentation_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in list(_SIGNATURES.items()) + list(_SEG_SIGNATURES.items()):
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    lib().avl_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what or "libavl_hip call", rc, last_error()))
+
+
+def host_array(values, ctype):
+    """A ctypes array holding `values` (flattened); keep the return value alive across the call."""
+    flat = [v for v in values]
+    return (ctype * len(flat))(*flat)

@@ -1,0 +1,128 @@
+"""Configuration tree with the reference's key names.
+
+Mirrors src/config/base_cfg.py:12-112 (which embeds the network tree of
+src/network/deeplab_v3_plus/config/demo.py:5-44 and deeplab_v3_plus.py:1-34).  yacs is not
+available offline, so ``CfgNode`` here is a small attribute-dict with the three yacs operations the
+reference uses: ``clone()``, ``merge_from_file(yaml)`` and ``merge_from_list([k, v, ...])``.
+Unknown keys in an override file raise ``KeyError`` (as yacs does).
+"""
+import copy
+
+import yaml
+
+from .labels import LABELS, LABELS_NAMES, LABEL_COLORS
+
+
+class CfgNode(dict):
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        self[name] = value
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+    def _merge(self, other, path=""):
+        for k, v in other.items():
+            if k not in self:
+                raise KeyError("Non-existent config key: %s%s" % (path, k))
+            if isinstance(self[k], CfgNode):
+                if not isinstance(v, dict):
+                    raise ValueError("config key %s%s expects a mapping" % (path, k))
+                self[k]._merge(v, path + k + ".")
+            else:
+                self[k] = v
+
+    def merge_from_file(self, filename):
+        with open(filename) as f:
+            data = yaml.safe_load(f) or {}
+        self._merge(data)
+
+    def merge_from_list(self, kv):
+        assert len(kv) % 2 == 0
+        for key, value in zip(kv[0::2], kv[1::2]):
+            node = self
+            parts = key.split(".")
+            for p in parts[:-1]:
+                node = node[p]
+            if parts[-1] not in node:
+                raise KeyError("Non-existent config key: %s" % key)
+            node[parts[-1]] = value
+
+    def __str__(self):
+        return yaml.safe_dump(_plain(self), default_flow_style=False)
+
+
+def _plain(node):
+    if isinstance(node, dict):
+        return {k: _plain(v) for k, v in node.items()}
+    if isinstance(node, (list, tuple)):
+        return [_plain(v) for v in node]
+    return node
+
+
+def get_network_cfg_defaults():
+    """demo.py:5-44 with the overrides of base_cfg.py:96-112."""
+    C = CfgNode()
+    C.OUTPUT_DIR = "@"
+    C.OUTPUT_NAME = ""
+    C.TRAIN_DATASET = "Mapillary"
+    C.DATASET_CONFIG = ""          # reference default points at the authors' NAS; "" = built-in 19-class table
+    C.DATASET = CfgNode()
+    C.DATASET.NAME = "AVL"
+    C.DATASET.IN_CHANNELS = 3
+    C.DATASET.NUM_CLASSES = 19
+    C.DATASET.ROOT_DIR = ""
+    C.MODEL = CfgNode()
+    C.MODEL.TYPE = "DeepLabv3+"
+    C.MODEL.WEIGHT = ""            # reference default is a NAS path; "" = seeded random weights
+    C.MODEL.SYNC_BN = False
+    C.MODEL.BACKBONE = "resnext50_32x4d"
+    C.MODEL.OUTPUT_STRIDE = 8
+    C.MODEL.ASPP = CfgNode()
+    C.MODEL.ASPP.OUT_CHANNELS = 256
+    C.MODEL.ASPP.ATROUS_CHANNELS = [256, 256, 256, 256]
+    C.MODEL.ASPP.ATROUS_KERNEL_SIZE = [1, 3, 3, 3]
+    C.MODEL.ASPP.ATROUS_DILATION = [1, 6, 12, 18]   # ignored: deeplab_v3_plus.py:30-36 picks by OUTPUT_STRIDE
+    C.MODEL.ASPP.DROPOUT = 0.5
+    C.MODEL.DECODER = CfgNode()
+    C.MODEL.DECODER.LOW_LEVEL_OUT_CHANNELS = 256
+    C.MODEL.DECODER.REFINE_CHANNELS = [256, 256]
+    C.MODEL.DECODER.REFINE_KERNEL_SIZE = [3, 3]
+    # build-specific (not in the reference): activation precision of the HIP conv stack
+    C.MODEL.PRECISION = "bf16"     # "bf16" (MFMA bf16, fp32 accumulate) or "f32" (fp32-input MFMA)
+    C.MODEL.SEED = 0               # seed of the random weights used when MODEL.WEIGHT == ""
+    return C
+
+
+def get_cfg_defaults():
+    """base_cfg.py:15-18 -- a fresh clone of the defaults."""
+    C = CfgNode()
+    C.TASK_NAME = "cfn_mtx_with_intensity"
+    C.OUTPUT_DIR = "@/outputs"
+    C.TEST_END_TIME = 1581541450
+    C.GROUND_TRUTH_DIR = ""
+    C.RNG_SEED = -1
+    C.LABELS = list(LABELS)
+    C.LABELS_NAMES = list(LABELS_NAMES)
+    C.LABEL_COLORS = [list(c) for c in LABEL_COLORS]
+    C.MAPPING = CfgNode()
+    C.MAPPING.RESOLUTION = 0.1
+    C.MAPPING.BOUNDARY = [[100, 300], [800, 1000]]
+    C.MAPPING.DEPTH_METHOD = "points_map"
+    C.MAPPING.PCD = CfgNode()
+    C.MAPPING.PCD.USE_INTENSITY = True
+    C.MAPPING.PCD.RANGE_MAX = 100.0
+    C.MAPPING.CONFUSION_MTX = CfgNode()
+    C.MAPPING.CONFUSION_MTX.LOAD_PATH = ""
+    C.MAPPING.INPUT_DIR = ""
+    # build-specific: element type of the grid on the GPU ("f64" = the reference's, "f32")
+    C.MAPPING.GRID_DTYPE = "f64"
+    C.VISION_SEM_SEG = CfgNode()
+    C.VISION_SEM_SEG.IMAGE_SCALE = 1.0
+    C.VISION_SEM_SEG.SEM_SEG_NETWORK = get_network_cfg_defaults()
+    return C

@@ -1,0 +1,547 @@
+// LiDAR -> image -> BEV grid kernels (gfx950).  Compiled with -ffp-contract=off: the float64
+// arithmetic below has to round exactly where the reference's NumPy does, so every fused
+// multiply-add is written out.
+//
+// Reference arithmetic (src/mapping.py):
+//   :371  Xv  = T @ [x y z 1]^T            (np.matmul -> OpenBLAS dgemm, K = 4: p0*x0 then an FMA chain)
+//   :375  IXY = ((P @ Xv)[0:2] / (P @ Xv)[2]).astype(int32)
+//   :378  0 < Xv.x < RANGE_MAX             :381-383 0 <= IX < W, 0 <= IY < H
+//   :405-411 cell = (((x,y) + offset) - (b00,b10)) / res -> astype(int32), on-grid test
+//   :419-437 per class: R,G colour match, buffered += of CM[:, i] (once per cell), lane bonus
+//
+// Kernels are HBM/latency bound integer + f64 work: one point per lane, coalesced 16 B (f32 AoS)
+// or 8 B (f64 SoA) loads, a label gather served by L2, and an idempotent atomicOr per point.
+#include "avl_common.h"
+
+#include <climits>
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct ProjParams {
+    double P[12];
+    double T[16];
+    int has_T;
+    double range_max;
+    int img_w, img_h;
+};
+
+struct PtsView {
+    const char* base;
+    int n;
+    int dtype;
+    long long point_stride, comp_stride;
+    int aos_f32;  // 1: float4-per-point fast path (16-byte aligned, comp_stride 4, point_stride 16)
+};
+
+struct GridParams {
+    double off_x, off_y, b00, b10, resolution;
+    int Hm, Wm, C;
+    unsigned bonus_classes;
+    unsigned char colors[AVL_MAX_MAP_CLASSES * 3];
+};
+
+struct CmParams {
+    double cm[AVL_MAX_MAP_CLASSES * AVL_MAX_MAP_CLASSES];  // row-major [C][C]
+};
+
+struct LutParams {
+    unsigned lut[256];
+};
+
+__device__ __forceinline__ void load_point(const PtsView& v, int k, double& x, double& y, double& z, double& it) {
+    if (v.aos_f32) {
+        const float4 p = *reinterpret_cast<const float4*>(v.base + (long long)k * 16);
+        x = (double)p.x; y = (double)p.y; z = (double)p.z; it = (double)p.w;
+        return;
+    }
+    const char* p = v.base + (long long)k * v.point_stride;
+    if (v.dtype == AVL_F64) {
+        x = *reinterpret_cast<const double*>(p);
+        y = *reinterpret_cast<const double*>(p + v.comp_stride);
+        z = *reinterpret_cast<const double*>(p + 2 * v.comp_stride);
+        it = *reinterpret_cast<const double*>(p + 3 * v.comp_stride);
+    } else {
+        x = (double)*reinterpret_cast<const float*>(p);
+        y = (double)*reinterpret_cast<const float*>(p + v.comp_stride);
+        z = (double)*reinterpret_cast<const float*>(p + 2 * v.comp_stride);
+        it = (double)*reinterpret_cast<const float*>(p + 3 * v.comp_stride);
+    }
+}
+
+// float64 -> int32 as NumPy on x86-64 does it (cvttsd2si): truncate toward zero; NaN, +-inf and
+// anything that does not fit yield INT_MIN.  v_cvt_i32_f64 would saturate / give 0.
+__device__ __forceinline__ int cvt_i32_numpy(double v) {
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return INT_MIN;
+    return (int)v;
+}
+
+// dot of a 4-vector row with (a,b,c,d) in OpenBLAS's order: r0*a, then fma chain.
+__device__ __forceinline__ double dot4(const double* r, double a, double b, double c, double d) {
+    double s = r[0] * a;
+    s = __builtin_fma(r[1], b, s);
+    s = __builtin_fma(r[2], c, s);
+    s = __builtin_fma(r[3], d, s);
+    return s;
+}
+
+__device__ __forceinline__ bool project(const ProjParams& pp, double x, double y, double z, int& ix, int& iy) {
+    double v0 = x, v1 = y, v2 = z, v3 = 1.0;
+    if (pp.has_T) {
+        v0 = dot4(pp.T + 0, x, y, z, 1.0);
+        v1 = dot4(pp.T + 4, x, y, z, 1.0);
+        v2 = dot4(pp.T + 8, x, y, z, 1.0);
+        v3 = dot4(pp.T + 12, x, y, z, 1.0);
+    }
+    const double p0 = dot4(pp.P + 0, v0, v1, v2, v3);
+    const double p1 = dot4(pp.P + 4, v0, v1, v2, v3);
+    const double p2 = dot4(pp.P + 8, v0, v1, v2, v3);
+    ix = cvt_i32_numpy(p0 / p2);
+    iy = cvt_i32_numpy(p1 / p2);
+    const bool positive = (0.0 < v0) && (v0 < pp.range_max);
+    return positive && ix >= 0 && ix < pp.img_w && iy >= 0 && iy < pp.img_h;
+}
+
+// grid cell of a point in its ORIGINAL frame (:404-411); -1 if off-grid / non-finite
+__device__ __forceinline__ int grid_cell(const GridParams& g, double x, double y, double z) {
+    const double xl = x + g.off_x, yl = y + g.off_y, zl = z + 0.0;
+    // :406 subtracts 0*z-like terms built from every coordinate: one non-finite coordinate makes both NaN
+    if (!(__builtin_isfinite(xl) && __builtin_isfinite(yl) && __builtin_isfinite(zl))) return -1;
+    const int cx = cvt_i32_numpy((xl - g.b00) / g.resolution);
+    const int cy = cvt_i32_numpy((yl - g.b10) / g.resolution);
+    if (cx < 0 || cx >= g.Hm || cy < 0 || cy >= g.Wm) return -1;
+    return cx * g.Wm + cy;
+}
+
+__device__ __forceinline__ unsigned vote_from_rg(const GridParams& g, unsigned r, unsigned gch) {
+    unsigned vote = 0;
+    for (int i = 0; i < g.C; ++i)
+        if (g.colors[3 * i] == r && g.colors[3 * i + 1] == gch) vote |= 1u << i;  // blue ignored (Q2)
+    return vote;
+}
+
+__device__ __forceinline__ unsigned add_bonus(unsigned vote, unsigned bonus_classes, double intensity) {
+    if ((vote & bonus_classes) && (intensity < 2.0 || intensity > 14.0)) vote |= (vote & bonus_classes) << 16;
+    return vote;
+}
+
+// OR the vote into the cell; the lane that turns the mask non-zero records the cell.  The append
+// counter is bumped once per wave (ballot + popcount) instead of once per lane.
+__device__ __forceinline__ void cast_vote(unsigned* cell_mask, int* touched, int* counter, int cell, unsigned vote) {
+    bool first = false;
+    if (cell >= 0 && vote != 0) first = (atomicOr(&cell_mask[cell], vote) == 0u);
+    const unsigned long long m = __ballot(first);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(counter, __builtin_popcountll(m));
+    base = __shfl(base, __builtin_ctzll(m));
+    if (first) touched[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = cell;
+}
+
+// ---------------------------------------------------------------- projection only (:367-383)
+__global__ void __launch_bounds__(kBlock) k_project_points(PtsView pv, ProjParams pp, int* __restrict__ out_ixy,
+                                                           unsigned char* __restrict__ out_mask) {
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= pv.n) return;
+    double x, y, z, it;
+    load_point(pv, k, x, y, z, it);
+    int ix, iy;
+    const bool ok = project(pp, x, y, z, ix, iy);
+    if (out_ixy) {
+        out_ixy[k] = ix;
+        out_ixy[pv.n + k] = iy;
+    }
+    if (out_mask) out_mask[k] = ok ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- project_pcd with compaction
+// pass 1: mask + pixel per point, survivors per block
+__global__ void __launch_bounds__(kBlock) k_pcd_mask(PtsView pv, ProjParams pp, int* __restrict__ pix,
+                                                     int* __restrict__ block_count) {
+    __shared__ int wave_cnt[kBlock / 64];
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    bool ok = false;
+    if (k < pv.n) {
+        double x, y, z, it;
+        load_point(pv, k, x, y, z, it);
+        int ix, iy;
+        ok = project(pp, x, y, z, ix, iy);
+        pix[k] = ok ? iy * pp.img_w + ix : -1;
+    }
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int w = 0; w < kBlock / 64; ++w) s += wave_cnt[w];
+        block_count[blockIdx.x] = s;
+    }
+}
+
+// pass 2: exclusive scan of the block counts (one workgroup), total -> out_count
+__global__ void __launch_bounds__(1024) k_scan_blocks(int* __restrict__ block_count, int nb, int* __restrict__ out_count) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int lo = t * per, hi = min(lo + per, nb);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += block_count[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        int v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;  // exclusive prefix of this thread's chunk
+    for (int i = lo; i < hi; ++i) {
+        const int c = block_count[i];
+        block_count[i] = run;
+        run += c;
+    }
+    if (t == 1023) *out_count = part[1023];
+}
+
+// pass 3: order-preserving scatter of the survivors + RGB gather (:385-387)
+__global__ void __launch_bounds__(kBlock) k_pcd_scatter(PtsView pv, const int* __restrict__ pix,
+                                                        const int* __restrict__ block_off,
+                                                        const unsigned char* __restrict__ image,
+                                                        double* __restrict__ out_pcd, unsigned char* __restrict__ out_label,
+                                                        long long out_ld) {
+    __shared__ int wave_cnt[kBlock / 64];
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    const int p = (k < pv.n) ? pix[k] : -1;
+    const bool ok = p >= 0;
+    const unsigned long long m = __ballot(ok);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wave] = __builtin_popcountll(m);
+    __syncthreads();
+    if (!ok) return;
+    int dst = block_off[blockIdx.x] + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) dst += wave_cnt[w];
+    double x, y, z, it;
+    load_point(pv, k, x, y, z, it);
+    out_pcd[dst] = x;
+    out_pcd[out_ld + dst] = y;
+    out_pcd[2 * out_ld + dst] = z;
+    out_pcd[3 * out_ld + dst] = it;
+    const unsigned char* px = image + 3ll * p;
+    out_label[dst] = px[0];
+    out_label[out_ld + dst] = px[1];
+    out_label[2 * out_ld + dst] = px[2];
+}
+
+// ---------------------------------------------------------------- update_map front end (:403-437)
+__global__ void __launch_bounds__(kBlock) k_vote_labelled(const double* __restrict__ pcd, const unsigned char* __restrict__ label,
+                                                          long long ld, int m_host, const int* __restrict__ m_dev,
+                                                          GridParams g, unsigned* __restrict__ cell_mask,
+                                                          int* __restrict__ touched, int* __restrict__ counter) {
+    const int m = m_dev ? min(*m_dev, m_host) : m_host;
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    int cell = -1;
+    unsigned vote = 0;
+    if (k < m) {
+        cell = grid_cell(g, pcd[k], pcd[ld + k], pcd[2 * ld + k]);
+        if (cell >= 0) {
+            vote = vote_from_rg(g, label[k], label[ld + k]);
+            vote = add_bonus(vote, g.bonus_classes, pcd[3 * ld + k]);
+        }
+    }
+    cast_vote(cell_mask, touched, counter, cell, vote);
+}
+
+// ---------------------------------------------------------------- fused project + vote
+template <int SRC>
+__global__ void __launch_bounds__(kBlock) k_fused_vote(PtsView pv, ProjParams pp, GridParams g,
+                                                       const unsigned char* __restrict__ src, int src_w, int src_h,
+                                                       LutParams lut, unsigned* __restrict__ cell_mask,
+                                                       int* __restrict__ touched, int* __restrict__ counter) {
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    int cell = -1;
+    unsigned vote = 0;
+    if (k < pv.n) {
+        double x, y, z, it;
+        load_point(pv, k, x, y, z, it);
+        int ix, iy;
+        if (project(pp, x, y, z, ix, iy)) {
+            cell = grid_cell(g, x, y, z);
+            if (cell >= 0) {
+                if (SRC == AVL_SRC_RGB) {
+                    const unsigned char* px = src + 3ll * ((long long)iy * src_w + ix);
+                    vote = vote_from_rg(g, px[0], px[1]);
+                } else {
+                    // cv2 INTER_NEAREST source index: min(floor(d * (src/dst)), src - 1), double arithmetic
+                    int sx = ix, sy = iy;
+                    if (src_w != pp.img_w) sx = min((int)__builtin_floor((double)ix * ((double)src_w / (double)pp.img_w)), src_w - 1);
+                    if (src_h != pp.img_h) sy = min((int)__builtin_floor((double)iy * ((double)src_h / (double)pp.img_h)), src_h - 1);
+                    vote = lut.lut[src[(long long)sy * src_w + sx]];
+                }
+                vote = add_bonus(vote, g.bonus_classes, it);
+            }
+        }
+    }
+    cast_vote(cell_mask, touched, counter, cell, vote);
+}
+
+// ---------------------------------------------------------------- touched cells -> grid (:424,437)
+// One lane per touched cell: adds CM[:, i] for every class bit in reference order, the bonus right
+// after its class, clears the mask.  Each cell appears once in `touched`, so no atomics on the map.
+template <typename MapT>
+__global__ void __launch_bounds__(kBlock) k_grid_apply(MapT* __restrict__ map, MapT* __restrict__ rows, int C, CmParams cm,
+                                                       unsigned* __restrict__ cell_mask, const int* __restrict__ touched,
+                                                       const int* __restrict__ counter) {
+    const int n = *counter;
+    for (int k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+        const int cell = touched[k];
+        const unsigned m = cell_mask[cell];
+        cell_mask[cell] = 0u;
+        MapT* row = rows ? rows + (long long)k * C : map + (long long)cell * C;
+        double v[AVL_MAX_MAP_CLASSES];
+#pragma unroll
+        for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
+            if (c < C) v[c] = (double)row[c];
+        for (int i = 0; i < C; ++i) {
+            if (m & (1u << i)) {
+#pragma unroll
+                for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
+                    if (c < C) v[c] = (double)(MapT)(v[c] + cm.cm[c * C + i]);
+            }
+            if (m & (1u << (16 + i))) {
+#pragma unroll
+                for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
+                    if (c == i) v[c] = (double)(MapT)(v[c] + 2.0);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
+            if (c < C) row[c] = (MapT)v[c];
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_colorize(const unsigned char* __restrict__ labels, int lw, int lh,
+                                                     const unsigned* __restrict__ pal_packed_dummy, LutParams pal,
+                                                     unsigned char* __restrict__ out, int out_w, int out_h) {
+    (void)pal_packed_dummy;
+    const long long idx = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= (long long)out_w * out_h) return;
+    const int dx = (int)(idx % out_w), dy = (int)(idx / out_w);
+    int sx = dx, sy = dy;
+    if (lw != out_w) sx = min((int)__builtin_floor((double)dx * ((double)lw / (double)out_w)), lw - 1);
+    if (lh != out_h) sy = min((int)__builtin_floor((double)dy * ((double)lh / (double)out_h)), lh - 1);
+    const unsigned c = pal.lut[labels[(long long)sy * lw + sx]];
+    out[3 * idx + 0] = (unsigned char)(c & 255u);
+    out[3 * idx + 1] = (unsigned char)((c >> 8) & 255u);
+    out[3 * idx + 2] = (unsigned char)((c >> 16) & 255u);
+}
+
+// ---------------------------------------------------------------- host helpers
+int fill_proj(ProjParams& pp, const double* P, const double* T, double range_max, int img_w, int img_h) {
+    if (!P) return avl::set_error(AVL_E_ARG, "P_host is NULL");
+    if (img_w <= 0 || img_h <= 0) return avl::set_error(AVL_E_ARG, "image size %dx%d", img_w, img_h);
+    memcpy(pp.P, P, sizeof(pp.P));
+    pp.has_T = T ? 1 : 0;
+    if (T) memcpy(pp.T, T, sizeof(pp.T));
+    else memset(pp.T, 0, sizeof(pp.T));
+    pp.range_max = range_max;
+    pp.img_w = img_w;
+    pp.img_h = img_h;
+    return AVL_OK;
+}
+
+int fill_pts(PtsView& pv, const void* pts, int n, int dtype, int64_t point_stride, int64_t comp_stride) {
+    if (n < 0) return avl::set_error(AVL_E_ARG, "n = %d", n);
+    if (n > 0 && !pts) return avl::set_error(AVL_E_ARG, "pts is NULL");
+    if (dtype != AVL_F32 && dtype != AVL_F64) return avl::set_error(AVL_E_ARG, "point dtype %d", dtype);
+    const int64_t es = dtype == AVL_F64 ? 8 : 4;
+    if (point_stride % es || comp_stride % es || point_stride <= 0 || comp_stride <= 0)
+        return avl::set_error(AVL_E_ARG, "point strides %lld/%lld not multiples of %lld", (long long)point_stride,
+                              (long long)comp_stride, (long long)es);
+    pv.base = static_cast<const char*>(pts);
+    pv.n = n;
+    pv.dtype = dtype;
+    pv.point_stride = point_stride;
+    pv.comp_stride = comp_stride;
+    pv.aos_f32 = (dtype == AVL_F32 && point_stride == 16 && comp_stride == 4 && (reinterpret_cast<uintptr_t>(pts) & 15) == 0);
+    return AVL_OK;
+}
+
+int fill_grid(GridParams& gp, const avl_grid* g, const uint8_t* colors, uint32_t bonus) {
+    if (!g || !g->map || !g->cell_mask || !g->touched || !g->counter) return avl::set_error(AVL_E_ARG, "avl_grid has NULL members");
+    if (g->Hm <= 0 || g->Wm <= 0 || g->C <= 0 || g->C > AVL_MAX_MAP_CLASSES)
+        return avl::set_error(AVL_E_ARG, "grid %dx%dx%d (C must be 1..%d)", g->Hm, g->Wm, g->C, AVL_MAX_MAP_CLASSES);
+    if ((long long)g->Hm * g->Wm > 0x7fffffffLL) return avl::set_error(AVL_E_ARG, "grid has more than 2^31 cells");
+    if (g->map_dtype != AVL_F32 && g->map_dtype != AVL_F64) return avl::set_error(AVL_E_ARG, "map dtype %d", g->map_dtype);
+    if (!(g->resolution > 0.0)) return avl::set_error(AVL_E_ARG, "resolution %g", g->resolution);
+    if (bonus >> g->C) return avl::set_error(AVL_E_ARG, "bonus_classes has bits beyond C");
+    gp.off_x = g->off_x; gp.off_y = g->off_y; gp.b00 = g->b00; gp.b10 = g->b10; gp.resolution = g->resolution;
+    gp.Hm = g->Hm; gp.Wm = g->Wm; gp.C = g->C;
+    gp.bonus_classes = bonus;
+    memset(gp.colors, 0, sizeof(gp.colors));
+    if (colors) memcpy(gp.colors, colors, 3 * g->C);
+    return AVL_OK;
+}
+
+int launch_apply(const avl_grid* g, const double* cm_host, void* rows, int rows_dtype, hipStream_t s) {
+    if (!cm_host) return avl::set_error(AVL_E_ARG, "cm_host is NULL");
+    const int dt = rows ? rows_dtype : g->map_dtype;
+    if (dt != AVL_F32 && dt != AVL_F64) return avl::set_error(AVL_E_ARG, "rows dtype %d", dt);
+    CmParams cm;
+    memset(&cm, 0, sizeof(cm));
+    memcpy(cm.cm, cm_host, sizeof(double) * g->C * g->C);
+    const int cap = g->touched_cap;
+    int blocks = (cap + kBlock - 1) / kBlock;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    if (dt == AVL_F64)
+        hipLaunchKernelGGL(k_grid_apply<double>, dim3(blocks), dim3(kBlock), 0, s, static_cast<double*>(g->map),
+                           static_cast<double*>(rows), g->C, cm, g->cell_mask, g->touched, g->counter);
+    else
+        hipLaunchKernelGGL(k_grid_apply<float>, dim3(blocks), dim3(kBlock), 0, s, static_cast<float*>(g->map),
+                           static_cast<float*>(rows), g->C, cm, g->cell_mask, g->touched, g->counter);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+extern "C" int avl_project_points(const void* pts, int n, int dtype, int64_t point_stride, int64_t comp_stride,
+                                  const double* P_host, const double* T_host, double range_max, int img_w, int img_h,
+                                  int32_t* out_ixy, uint8_t* out_mask, void* stream) {
+    PtsView pv;
+    ProjParams pp;
+    int rc;
+    if ((rc = fill_pts(pv, pts, n, dtype, point_stride, comp_stride))) return rc;
+    if ((rc = fill_proj(pp, P_host, T_host, range_max, img_w, img_h))) return rc;
+    if (n == 0) return AVL_OK;
+    hipLaunchKernelGGL(k_project_points, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, avl::as_stream(stream), pv, pp,
+                       out_ixy, out_mask);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+extern "C" int64_t avl_project_pcd_scratch_bytes(int n) {
+    if (n < 0) return 0;
+    const int64_t nb = (n + kBlock - 1) / kBlock;
+    return (int64_t)sizeof(int) * ((int64_t)n + nb + 16);
+}
+
+extern "C" int avl_project_pcd(const void* pts, int n, int dtype, int64_t point_stride, int64_t comp_stride,
+                               const double* P_host, const double* T_host, double range_max, const uint8_t* image,
+                               int img_w, int img_h, double* out_pcd, uint8_t* out_label, int64_t out_ld,
+                               int32_t* out_count, void* scratch, void* stream) {
+    PtsView pv;
+    ProjParams pp;
+    int rc;
+    if ((rc = fill_pts(pv, pts, n, dtype, point_stride, comp_stride))) return rc;
+    if ((rc = fill_proj(pp, P_host, T_host, range_max, img_w, img_h))) return rc;
+    AVL_REQUIRE(out_count, "out_count is NULL");
+    hipStream_t s = avl::as_stream(stream);
+    if (n == 0) {
+        AVL_HIP_CHECK(hipMemsetAsync(out_count, 0, sizeof(int), s));
+        return AVL_OK;
+    }
+    AVL_REQUIRE(image && out_pcd && out_label && scratch, "NULL buffer");
+    AVL_REQUIRE(out_ld >= n, "out_ld %lld < n %d", (long long)out_ld, n);
+    AVL_REQUIRE((long long)img_w * img_h < 0x7fffffffLL, "image too large");
+    const int nb = (n + kBlock - 1) / kBlock;
+    int* pix = static_cast<int*>(scratch);
+    int* block_count = pix + n;
+    hipLaunchKernelGGL(k_pcd_mask, dim3(nb), dim3(kBlock), 0, s, pv, pp, pix, block_count);
+    AVL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, block_count, nb, out_count);
+    AVL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pcd_scatter, dim3(nb), dim3(kBlock), 0, s, pv, pix, block_count, image, out_pcd, out_label,
+                       (long long)out_ld);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+extern "C" int avl_vote_points(const avl_grid* g, const double* pcd, const uint8_t* label, int64_t ld, int m_host,
+                               const int32_t* m_dev, const uint8_t* label_colors_host, uint32_t bonus_classes,
+                               void* stream) {
+    GridParams gp;
+    int rc;
+    AVL_REQUIRE(label_colors_host, "label_colors_host is NULL");
+    if ((rc = fill_grid(gp, g, label_colors_host, bonus_classes))) return rc;
+    AVL_REQUIRE(m_host >= 0, "m = %d", m_host);
+    hipStream_t s = avl::as_stream(stream);
+    AVL_HIP_CHECK(hipMemsetAsync(g->counter, 0, 16, s));
+    if (m_host == 0) return AVL_OK;
+    AVL_REQUIRE(pcd && label, "NULL buffer");
+    AVL_REQUIRE(ld >= m_host, "ld %lld < m %d", (long long)ld, m_host);
+    AVL_REQUIRE(g->touched_cap >= (m_host < g->Hm * g->Wm ? m_host : g->Hm * g->Wm), "touched_cap %d too small", g->touched_cap);
+    hipLaunchKernelGGL(k_vote_labelled, dim3((m_host + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pcd, label, (long long)ld,
+                       m_host, m_dev, gp, g->cell_mask, g->touched, g->counter);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+extern "C" int avl_grid_apply(const avl_grid* g, const double* cm_host, void* rows, int rows_dtype, void* stream) {
+    AVL_REQUIRE(g && g->cell_mask && g->touched && g->counter && (rows || g->map), "avl_grid has NULL members");
+    AVL_REQUIRE(g->C > 0 && g->C <= AVL_MAX_MAP_CLASSES, "C = %d", g->C);
+    return launch_apply(g, cm_host, rows, rows_dtype, avl::as_stream(stream));
+}
+
+extern "C" int avl_update_map(const avl_grid* g, const double* pcd, const uint8_t* label, int64_t ld, int m_host,
+                              const int32_t* m_dev, const uint8_t* label_colors_host, const double* cm_host,
+                              uint32_t bonus_classes, void* stream) {
+    AVL_REQUIRE(cm_host, "cm_host is NULL");
+    int rc = avl_vote_points(g, pcd, label, ld, m_host, m_dev, label_colors_host, bonus_classes, stream);
+    if (rc) return rc;
+    return launch_apply(g, cm_host, nullptr, 0, avl::as_stream(stream));
+}
+
+extern "C" int avl_fused_frame(const avl_grid* g, const void* pts, int n, int dtype, int64_t point_stride,
+                               int64_t comp_stride, const double* P_host, const double* T_host, double range_max,
+                               int src_kind, const uint8_t* src, int src_w, int src_h, int img_w, int img_h,
+                               const uint32_t* lut_host, const uint8_t* label_colors_host, const double* cm_host,
+                               uint32_t bonus_classes, void* stream) {
+    PtsView pv;
+    ProjParams pp;
+    GridParams gp;
+    LutParams lut;
+    int rc;
+    if ((rc = fill_pts(pv, pts, n, dtype, point_stride, comp_stride))) return rc;
+    if ((rc = fill_proj(pp, P_host, T_host, range_max, img_w, img_h))) return rc;
+    if ((rc = fill_grid(gp, g, label_colors_host, bonus_classes))) return rc;
+    AVL_REQUIRE(src_kind == AVL_SRC_RGB || src_kind == AVL_SRC_CLASSMAP, "src_kind %d", src_kind);
+    AVL_REQUIRE(src && src_w > 0 && src_h > 0, "bad semantic source");
+    memset(&lut, 0, sizeof(lut));
+    if (src_kind == AVL_SRC_RGB) {
+        AVL_REQUIRE(label_colors_host, "label_colors_host is NULL");
+        AVL_REQUIRE(src_w == img_w && src_h == img_h, "RGB source must be %dx%d", img_w, img_h);
+    } else {
+        AVL_REQUIRE(lut_host, "lut_host is NULL");
+        memcpy(lut.lut, lut_host, sizeof(lut.lut));
+    }
+    if (n == 0) return AVL_OK;
+    AVL_REQUIRE(g->touched_cap >= (n < g->Hm * g->Wm ? n : g->Hm * g->Wm), "touched_cap %d too small", g->touched_cap);
+    hipStream_t s = avl::as_stream(stream);
+    AVL_HIP_CHECK(hipMemsetAsync(g->counter, 0, 16, s));
+    const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
+    if (src_kind == AVL_SRC_RGB)
+        hipLaunchKernelGGL(k_fused_vote<AVL_SRC_RGB>, grid, block, 0, s, pv, pp, gp, src, src_w, src_h, lut, g->cell_mask,
+                           g->touched, g->counter);
+    else
+        hipLaunchKernelGGL(k_fused_vote<AVL_SRC_CLASSMAP>, grid, block, 0, s, pv, pp, gp, src, src_w, src_h, lut,
+                           g->cell_mask, g->touched, g->counter);
+    AVL_LAUNCH_CHECK();
+    return launch_apply(g, cm_host, nullptr, 0, s);
+}
+
+extern "C" int avl_colorize_labels(const uint8_t* labels, int lw, int lh, const uint8_t* palette_host, uint8_t* out,
+                                   int out_w, int out_h, void* stream) {
+    AVL_REQUIRE(labels && palette_host && out, "NULL buffer");
+    AVL_REQUIRE(lw > 0 && lh > 0 && out_w > 0 && out_h > 0, "bad sizes");
+    LutParams pal;
+    for (int k = 0; k < 256; ++k)
+        pal.lut[k] = (unsigned)palette_host[3 * k] | ((unsigned)palette_host[3 * k + 1] << 8) | ((unsigned)palette_host[3 * k + 2] << 16);
+    const long long total = (long long)out_w * out_h;
+    hipLaunchKernelGGL(k_colorize, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, avl::as_stream(stream),
+                       labels, lw, lh, nullptr, pal, out, out_w, out_h);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
