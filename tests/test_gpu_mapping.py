@@ -202,6 +202,7 @@ def test_full_size_properties(cuda_device):
         perm = rng.permutation(2 * n)
         sm.frame_device(np.concatenate([pcd, pcd], axis=1)[:, perm], "velodyne", img_d, None, cam)
         assert torch.equal(sm.map_dev, one)
-        # frames add: a second identical frame doubles every entry exactly (x + x is exact)
+        # frames accumulate: a second frame on top of the first, against the oracle doing the same
         sm.frame_device(pcd, "velodyne", img_d, None, cam)
-        assert torch.equal(sm.map_dev, one * 2)
+        mo.mapping_frame(grid, pcd, "velodyne", image, None, cam.P, cfg)
+        assert np.array_equal(sm.map, grid)

@@ -69,6 +69,10 @@ def lib():
             raise RuntimeError(
                 "libavl_hip.so not found at %s -- build it with `make -C vision_semantic_segmentation_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
+        # torch ships its own HIP/HSA runtime (same SONAME as /opt/rocm's).  It must be in the process
+        # first so that libavl_hip.so binds to that copy: two HSA runtimes in one process cannot
+        # both own the GPU ("no ROCm-capable device is detected").
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in list(_SIGNATURES.items()) + list(_SEG_SIGNATURES.items()):
             fn = getattr(handle, name)
