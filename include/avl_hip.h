@@ -133,6 +133,62 @@ int avl_fused_frame(const avl_grid* g, const void* pts, int n, int dtype, int64_
 int avl_colorize_labels(const uint8_t* labels, int lw, int lh, const uint8_t* palette_host,
                         uint8_t* out, int out_w, int out_h, void* stream);
 
+
+/* ---- a1-a5: segmentation forward (DeepLabV3+ / ResNeXt-50 OS8, eval mode) -------------------
+ *
+ * The reference builds the network from torch modules (src/semantic_segmentation.py:21-57,
+ * src/network/deeplab_v3_plus/models/{deeplab_v3_plus,aspp,decoder}.py, torchvision ResNet).  Here
+ * the Python host folds BatchNorm into the convolutions, lays activations out as NHWC
+ * ([H*W rows][channels], row stride `ld` elements, so channel slices of a wider buffer give
+ * torch.cat for free) and hands the library a flat list of ops; avl_seg_plan_run() launches them in
+ * order on one stream.  Activations are AVL_BF16 (bf16 MFMA, fp32 accumulate) or AVL_F32
+ * (fp32-input MFMA, the reference's precision).  Biases are always fp32.
+ *
+ * Every buffer named by an op must stay allocated while the plan lives; `*_rows` is the number of
+ * rows actually allocated (GEMM tiles read whole 128-row tiles, so M is padded up by the caller and
+ * the plan checks it). */
+
+#define AVL_OP_STEM 1        /* uint8 RGB [H][W][3] -> normalise (semantic_segmentation.py:35-39) -> 7x7 s2 p3 conv +bias+ReLU */
+#define AVL_OP_MAXPOOL 2     /* 3x3 s2 p1 (torchvision ResNet.maxpool)                                          */
+#define AVL_OP_GEMM 3        /* 1x1 conv: out[m][n] = act(sum_k in[row(m)][k] w[n][k] + bias[n] (+ in2[m][n])) */
+#define AVL_OP_GCONV 4       /* grouped 3x3 conv, stride 1|2, dilation d, pad d, +bias+ReLU (Bottleneck.conv2)  */
+#define AVL_OP_DWCONV 5      /* depthwise 3x3 conv, dilation d, pad p, +bias+ReLU (core/nn/modules/conv.py:131)  */
+#define AVL_OP_BILINEAR 6    /* F.interpolate(mode='bilinear', align_corners=True) (aspp.py:88, decoder.py:47)   */
+#define AVL_OP_GAP 7         /* AdaptiveAvgPool2d((1,1)) -> fp32 [C] (aspp.py:69)                                */
+#define AVL_OP_GEMV 8        /* out[n] = act(sum_k w[n][k] in[k] + bias[n]) on fp32 vectors (pooled branch)      */
+#define AVL_OP_ARGMAX 9      /* torch.argmax(dim=1) over fp32 logits [M][C] -> uint8 (semantic_segmentation.py:56) */
+#define AVL_OP_SUBSAMPLE 10  /* rows of a stride-s 1x1 conv's input (Bottleneck.downsample in layer2.0)          */
+
+typedef struct avl_seg_op {
+    int32_t kind;            /* AVL_OP_*                                                        */
+    int32_t dtype;           /* activation type of in/in2/out: AVL_BF16 or AVL_F32              */
+    const void* in;          /* input activation (STEM: uint8 image; GEMV/GAP-out: fp32)       */
+    const void* in2;         /* GEMM: residual added before the ReLU, or NULL                   */
+    void* out;
+    const void* weight;      /* packed by the host, layout per kind (see network.py)            */
+    const float* bias;       /* fp32 [out_c padded], or NULL                                    */
+    int32_t in_h, in_w, in_c, in_ld, in_rows;
+    int32_t out_h, out_w, out_c, out_ld, out_rows;
+    int32_t in2_ld;
+    int32_t ksize, stride, pad, dil, groups;
+    int32_t relu;
+    int32_t out_f32;         /* GEMM: write fp32 (the logits) instead of `dtype`                */
+    int32_t w_rows;          /* GEMM: rows of `weight` allocated (out_c padded to the N tile)   */
+    int32_t reserved[3];
+} avl_seg_op;
+
+typedef struct avl_seg_plan avl_seg_plan;
+
+/* copies the op list, validates shapes/strides/allocated rows against what the kernels read */
+int avl_seg_plan_create(const avl_seg_op* ops_host, int n_ops, avl_seg_plan** out_plan);
+void avl_seg_plan_destroy(avl_seg_plan* plan);
+/* launches every op on `stream` (no sync) */
+int avl_seg_plan_run(avl_seg_plan* plan, void* stream);
+/* same, with a hipEvent pair around every op; blocks until done; ms_host[n_ops] = op durations.
+ * flops_host / bytes_host (either may be NULL) receive each op's algorithmic flops and bytes. */
+int avl_seg_plan_profile(avl_seg_plan* plan, void* stream, float* ms_host, double* flops_host, double* bytes_host);
+int avl_seg_plan_num_ops(const avl_seg_plan* plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,112 @@
+"""HIP segmentation stack (through avl_seg_plan_*) against the torch-CPU fp32 oracle
+(oracle/network_oracle.py) on the full ResNeXt-50 / DeepLabV3+ architecture with seeded random
+weights (no trained weights exist offline; BN statistics are randomised so folding is exercised).
+
+Tolerances (north_star: logits within 1e-3 relative):
+  * MODEL.PRECISION = "f32"  (fp32-input MFMA): max|dlogit| / max|logit| <= 1e-3   -- the parity bar
+  * MODEL.PRECISION = "bf16" (the bench path):  bf16 keeps 8 significand bits per activation, so after
+    ~55 layers the logits carry a few 1e-2 of relative error; asserted <= 6e-2 and reported, with
+    arg-max agreement asserted >= 95 % (measured values are printed)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(precision):
+    from vision_semantic_segmentation_amd.config import get_network_cfg_defaults
+    cfg = get_network_cfg_defaults()
+    cfg.MODEL.PRECISION = precision
+    return cfg
+
+
+@pytest.fixture(scope="module")
+def state():
+    from vision_semantic_segmentation_amd.network import random_state_dict
+    return random_state_dict(0)
+
+
+def _compare(state, precision, h, w, device, seed=0):
+    import torch
+    from oracle import network_oracle as no
+    from vision_semantic_segmentation_amd import SemanticSegmentation
+    seg = SemanticSegmentation(_cfg(precision), device=device, state_dict=state)
+    img = np.random.default_rng(seed).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    got = seg.logits(img).cpu()
+    ref = no.forward_logits(state, img)[0]
+    assert tuple(got.shape) == tuple(ref.shape) == (19, h // 4 - 4, w // 4 - 4)
+    rel = float((got - ref).abs().max() / ref.abs().max())
+    agree = float((got.argmax(0) == ref.argmax(0)).float().mean())
+    labels = seg.segmentation(img)
+    assert labels.dtype == np.int64 and labels.shape == (h // 4 - 4, w // 4 - 4)
+    assert np.array_equal(labels, got.argmax(0).numpy())       # GPU arg-max == torch.argmax of the GPU logits
+    return rel, agree
+
+
+@pytest.mark.parametrize("hw", [(96, 128), (320, 416)])
+def test_f32_logits_within_1e3_of_oracle(state, hw, cuda_device):
+    rel, agree = _compare(state, "f32", hw[0], hw[1], cuda_device)
+    print("f32 %dx%d: max rel err %.3e, argmax agreement %.5f" % (hw[0], hw[1], rel, agree))
+    assert rel <= 1e-3
+    assert agree >= 0.999
+
+
+@pytest.mark.parametrize("hw", [(96, 128), (320, 416)])
+def test_bf16_logits_close_to_oracle(state, hw, cuda_device):
+    rel, agree = _compare(state, "bf16", hw[0], hw[1], cuda_device)
+    print("bf16 %dx%d: max rel err %.3e, argmax agreement %.5f" % (hw[0], hw[1], rel, agree))
+    assert rel <= 6e-2
+    assert agree >= 0.95
+
+
+def test_checkpoint_format_roundtrip(state, cuda_device, tmp_path):
+    """The reference's file format: {'model': state_dict} with DataParallel's 'module.' prefix."""
+    import torch
+    from vision_semantic_segmentation_amd import SemanticSegmentation
+    path = os.path.join(str(tmp_path), "model_best.pth")
+    torch.save({"model": {"module." + k: v for k, v in state.items()}, "epoch": 3}, path)
+    cfg = _cfg("bf16")
+    cfg.MODEL.WEIGHT = path
+    a = SemanticSegmentation(cfg, device=cuda_device)
+    b = SemanticSegmentation(_cfg("bf16"), device=cuda_device, state_dict=state)
+    img = np.random.default_rng(4).integers(0, 256, size=(64, 96, 3), dtype=np.uint8)
+    assert torch.equal(a.logits(img), b.logits(img))           # same weights -> bitwise identical, run to run
+    bad = dict(state)
+    bad.pop("aspp.conv.conv.weight")
+    with pytest.raises(KeyError):
+        SemanticSegmentation(_cfg("bf16"), device=cuda_device, state_dict=bad)
+
+
+def test_node_callback_and_fused_mapping(state, cuda_device):
+    """VisionSemanticSegmentationNode.image_callback -> colour image; its label map fed straight into the
+    fused mapping path equals mapping the published colour image (the reference's two-node route)."""
+    import torch
+    from oracle import mapping_oracle as mo
+    from vision_semantic_segmentation_amd import SemanticMapping, SemanticSegmentation, VisionSemanticSegmentationNode, get_cfg_defaults
+    from vision_semantic_segmentation_amd import synthetic as syn
+    from vision_semantic_segmentation_amd.camera import camera_setup_1
+    from vision_semantic_segmentation_amd.utils import Header, Message
+    from vision_semantic_segmentation_amd.utils.logger import MyLogger
+    cfg = get_cfg_defaults()
+    H, W = 240, 320
+    cfg.MAPPING.BOUNDARY = syn.centred_boundary(mo.PCD_ORIGIN_OFFSET[:2], 100.0)
+    cfg.MAPPING.RESOLUTION = 0.5
+    seg = SemanticSegmentation(cfg.VISION_SEM_SEG.SEM_SEG_NETWORK, device=cuda_device, state_dict=state)
+    node = VisionSemanticSegmentationNode(cfg, seg=seg)
+    rng = np.random.default_rng(8)
+    bgr = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    colour = node.image_callback(Message(Header(frame_id="camera1"), data=bgr))
+    assert colour.shape == (H, W, 3) and colour.dtype == np.uint8
+    labels = node.last_labels
+    assert tuple(labels.shape) == (H // 4 - 4, W // 4 - 4)
+    assert np.array_equal(colour, mo.semantic_image_from_labels(labels.cpu().numpy(), H, W))
+    cam = camera_setup_1().scaled(W / 1920.0, H / 1440.0)
+    pcd = syn.make_cloud(rng, 20000, cam.K, cam.R, cam.t, W, H)
+    a = SemanticMapping(cfg, device=cuda_device, logger=MyLogger("t", quiet=True))
+    b = SemanticMapping(cfg, device=cuda_device, logger=MyLogger("t", quiet=True))
+    a.frame_device(pcd, "velodyne", labels, None, cam, src_kind="classmap", image_size=(H, W))
+    b.pcd, b.pcd_frame_id = pcd, "velodyne"
+    b.mapping(colour, None, cam)
+    assert torch.equal(a.map_dev, b.map_dev) and float(a.map_dev.abs().sum()) > 0

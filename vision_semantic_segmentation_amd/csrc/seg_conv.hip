@@ -1,0 +1,420 @@
+// The non-GEMM layers of the segmentation network (gfx950): stem, max-pool, grouped 3x3,
+// depthwise 3x3, bilinear upsample, global average pool, the pooled branch's GEMVs, arg-max.
+// All are NHWC, 16-byte vector accesses along channels, fp32 arithmetic whatever the storage type.
+// Weights that every lane reads at the same address (stem, grouped conv) are left in global memory
+// on purpose: the address is wave-uniform, so hipcc fetches them through the scalar cache and the
+// inner loops are pure v_fmac with an SGPR operand.
+#include "seg_types.h"
+
+namespace avl {
+namespace {
+
+constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------------------------------ stem
+// semantic_segmentation.py:35-39 (ToTensor: u8/255, Normalize: (x-mean)/std) + torchvision
+// ResNet.conv1 (7x7, stride 2, pad 3, 3->64) + folded bn1 + ReLU.  Zero padding applies to the
+// NORMALISED image, so normalisation cannot be folded into the weights at the border.
+// weight: float [7][7][3][64]; one lane = one output pixel x 64 channels.
+template <typename T>
+__global__ void __launch_bounds__(kThreads) k_stem(const unsigned char* __restrict__ img, int H, int W,
+                                                  const float* __restrict__ w, const float* __restrict__ bias,
+                                                  T* __restrict__ out, int OH, int OW, int out_ld) {
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= OH * OW) return;
+    const int oy = idx / OW, ox = idx % OW;
+    float acc[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) acc[c] = bias[c];
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int ky = 0; ky < 7; ++ky) {
+        const int iy = oy * 2 - 3 + ky;
+        for (int kx = 0; kx < 7; ++kx) {
+            const int ix = ox * 2 - 3 + kx;
+            const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const unsigned char* px = img + 3ll * ((long long)(in ? iy : 0) * W + (in ? ix : 0));
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float x = in ? ((float)px[ci] / 255.0f - mean[ci]) / stdv[ci] : 0.0f;
+                const float* wr = w + ((ky * 7 + kx) * 3 + ci) * 64;
+#pragma unroll
+                for (int c = 0; c < 64; ++c) acc[c] = fmaf(x, wr[c], acc[c]);
+            }
+        }
+    }
+    T* op = out + (long long)idx * out_ld;
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(acc[c8 * 8 + i], 0.f);
+        Vec8<T>::store(op + c8 * 8, v);
+    }
+}
+
+// --------------------------------------------------------------------------------------- maxpool
+template <typename T>
+__global__ void __launch_bounds__(kThreads) k_maxpool(const T* __restrict__ in, int H, int W, int C, int in_ld,
+                                                     T* __restrict__ out, int OH, int OW, int out_ld) {
+    const int c8n = C / 8;
+    const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= (long long)OH * OW * c8n) return;
+    const int c8 = (int)(idx % c8n);
+    const int pix = (int)(idx / c8n), oy = pix / OW, ox = pix % OW;
+    float m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            if (ix < 0 || ix >= W) continue;
+            float v[8];
+            Vec8<T>::load(in + ((long long)iy * W + ix) * in_ld + c8 * 8, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], v[i]);
+        }
+    }
+    Vec8<T>::store(out + (long long)pix * out_ld + c8 * 8, m);
+}
+
+// ------------------------------------------------------------------------------- grouped 3x3 conv
+// torchvision Bottleneck.conv2 (groups = 32) + folded bn2 + ReLU.  weight: float
+// [group][tap = ky*3+kx][ci][co]; one lane = one output pixel of one group (CG in, CG out).
+template <typename T, int CG>
+__global__ void __launch_bounds__(kThreads) k_gconv(const T* __restrict__ in, int H, int W, int in_ld,
+                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                   T* __restrict__ out, int OH, int OW, int out_ld, int stride, int dil) {
+    const int g = blockIdx.y;
+    const int pix = blockIdx.x * kThreads + threadIdx.x;
+    if (pix >= OH * OW) return;
+    const int oy = pix / OW, ox = pix % OW;
+    float acc[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) acc[c] = bias[g * CG + c];
+    const float* wg = w + (long long)g * 9 * CG * CG;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * stride + (ky - 1) * dil;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * stride + (kx - 1) * dil;
+            if (ix < 0 || ix >= W) continue;
+            const T* ip = in + ((long long)iy * W + ix) * in_ld + g * CG;
+            float x[CG];
+            if constexpr (CG >= 8) {
+#pragma unroll
+                for (int c8 = 0; c8 < CG / 8; ++c8) {
+                    float v[8];
+                    Vec8<T>::load(ip + c8 * 8, v);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[c8 * 8 + i] = v[i];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CG; ++c) x[c] = to_f32(ip[c]);
+            }
+            const float* wt = wg + (ky * 3 + kx) * CG * CG;
+#pragma unroll
+            for (int ci = 0; ci < CG; ++ci)
+#pragma unroll
+                for (int co = 0; co < CG; ++co) acc[co] = fmaf(x[ci], wt[ci * CG + co], acc[co]);
+        }
+    }
+    T* op = out + (long long)pix * out_ld + g * CG;
+    if constexpr (CG >= 8) {
+#pragma unroll
+        for (int c8 = 0; c8 < CG / 8; ++c8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(acc[c8 * 8 + i], 0.f);
+            Vec8<T>::store(op + c8 * 8, v);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CG; ++c) op[c] = from_f32<T>(fmaxf(acc[c], 0.f));
+    }
+}
+
+// ------------------------------------------------------------------------------ depthwise 3x3 conv
+// core/nn/modules/conv.py:131-134 (groups = in_channels) + folded BN + ReLU.
+// weight: float [9][C]; one lane = one output pixel x 8 channels.
+template <typename T>
+__global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, int H, int W, int C, int in_ld,
+                                                    const float* __restrict__ w, const float* __restrict__ bias,
+                                                    T* __restrict__ out, int OH, int OW, int out_ld, int pad, int dil, int relu) {
+    const int c8n = C / 8;
+    const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= (long long)OH * OW * c8n) return;
+    const int c8 = (int)(idx % c8n);
+    const int pix = (int)(idx / c8n), oy = pix / OW, ox = pix % OW;
+    float acc[8];
+    {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + c8 * 8);
+        const float4 b1 = *reinterpret_cast<const float4*>(bias + c8 * 8 + 4);
+        acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w;
+        acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+    }
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy - pad + ky * dil;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox - pad + kx * dil;
+            if (ix < 0 || ix >= W) continue;
+            float v[8];
+            Vec8<T>::load(in + ((long long)iy * W + ix) * in_ld + c8 * 8, v);
+            const float* wt = w + (ky * 3 + kx) * C + c8 * 8;
+            const float4 w0 = *reinterpret_cast<const float4*>(wt);
+            const float4 w1 = *reinterpret_cast<const float4*>(wt + 4);
+            acc[0] = fmaf(v[0], w0.x, acc[0]); acc[1] = fmaf(v[1], w0.y, acc[1]);
+            acc[2] = fmaf(v[2], w0.z, acc[2]); acc[3] = fmaf(v[3], w0.w, acc[3]);
+            acc[4] = fmaf(v[4], w1.x, acc[4]); acc[5] = fmaf(v[5], w1.y, acc[5]);
+            acc[6] = fmaf(v[6], w1.z, acc[6]); acc[7] = fmaf(v[7], w1.w, acc[7]);
+        }
+    }
+    if (relu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaxf(acc[i], 0.f);
+    }
+    Vec8<T>::store(out + (long long)pix * out_ld + c8 * 8, acc);
+}
+
+// ------------------------------------------------------------------------------------- bilinear
+// F.interpolate(mode='bilinear', align_corners=True): src = dst * (in-1)/(out-1)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) k_bilinear(const T* __restrict__ in, int H, int W, int C, int in_ld,
+                                                      T* __restrict__ out, int OH, int OW, int out_ld) {
+    const int c8n = C / 8;
+    const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= (long long)OH * OW * c8n) return;
+    const int c8 = (int)(idx % c8n);
+    const int pix = (int)(idx / c8n), oy = pix / OW, ox = pix % OW;
+    const float sy = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+    const float sx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    const float fy = sy * oy, fx = sx * ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    float a[8], b[8], c[8], d[8], r[8];
+    Vec8<T>::load(in + ((long long)y0 * W + x0) * in_ld + c8 * 8, a);
+    Vec8<T>::load(in + ((long long)y0 * W + x1) * in_ld + c8 * 8, b);
+    Vec8<T>::load(in + ((long long)y1 * W + x0) * in_ld + c8 * 8, c);
+    Vec8<T>::load(in + ((long long)y1 * W + x1) * in_ld + c8 * 8, d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = hy * (hx * a[i] + lx * b[i]) + ly * (hx * c[i] + lx * d[i]);
+    Vec8<T>::store(out + (long long)pix * out_ld + c8 * 8, r);
+}
+
+// ---------------------------------------------------------------------------- global average pool
+// stage 1: block b sums rows b, b+G, b+2G, ... for its 8-channel chunks -> partial[b][C] (fp32)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) k_gap_partial(const T* __restrict__ in, int M, int C, int in_ld,
+                                                         float* __restrict__ partial) {
+    const int c8n = C / 8;
+    for (int c8 = threadIdx.x; c8 < c8n; c8 += kThreads) {
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = blockIdx.x; r < M; r += gridDim.x) {
+            float v[8];
+            Vec8<T>::load(in + (long long)r * in_ld + c8 * 8, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += v[i];
+        }
+        Vec8<float>::store(partial + (long long)blockIdx.x * C + c8 * 8, s);
+    }
+}
+// stage 2: fixed-order sum of the partials, divide by M
+__global__ void __launch_bounds__(kThreads) k_gap_final(const float* __restrict__ partial, int G, int C, int M,
+                                                       float* __restrict__ out) {
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += partial[(long long)g * C + c];
+    out[c] = s / (float)M;
+}
+
+// ------------------------------------------------------------------------------------------ gemv
+// out[n] = act(sum_k w[n][k] * in[k] + bias[n]); fp32; one wave per output.
+__global__ void __launch_bounds__(kThreads) k_gemv(const float* __restrict__ in, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, float* __restrict__ out, int N, int K, int relu) {
+    const int n = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s = fmaf(w[(long long)n * K + k], in[k], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) {
+        s += bias ? bias[n] : 0.f;
+        out[n] = relu ? fmaxf(s, 0.f) : s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- argmax
+// torch.argmax(dim=1): first maximal index wins on ties.
+__global__ void __launch_bounds__(kThreads) k_argmax(const float* __restrict__ logits, int M, int C, int ld,
+                                                    unsigned char* __restrict__ out) {
+    const int m = blockIdx.x * kThreads + threadIdx.x;
+    if (m >= M) return;
+    const float* p = logits + (long long)m * ld;
+    float best = p[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+        const float v = p[c];
+        if (v > best || (v != v && best == best)) { best = v; bi = c; }   // NaN counts as maximal, like torch
+    }
+    out[m] = (unsigned char)bi;
+}
+
+// ------------------------------------------------------------------------------------- subsample
+template <typename T>
+__global__ void __launch_bounds__(kThreads) k_subsample(const T* __restrict__ in, int W, int C, int in_ld,
+                                                       T* __restrict__ out, int OH, int OW, int out_ld, int stride) {
+    const int c8n = C / 8;
+    const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= (long long)OH * OW * c8n) return;
+    const int c8 = (int)(idx % c8n);
+    const int pix = (int)(idx / c8n), oy = pix / OW, ox = pix % OW;
+    float v[8];
+    Vec8<T>::load(in + ((long long)(oy * stride) * W + ox * stride) * in_ld + c8 * 8, v);
+    Vec8<T>::store(out + (long long)pix * out_ld + c8 * 8, v);
+}
+
+inline unsigned blocks_for(long long n) { return (unsigned)((n + kThreads - 1) / kThreads); }
+
+template <typename T>
+int launch_typed(const avl_seg_op& op, hipStream_t s) {
+    const T* in = static_cast<const T*>(op.in);
+    T* out = static_cast<T*>(op.out);
+    const float* w = static_cast<const float*>(op.weight);
+    switch (op.kind) {
+        case AVL_OP_STEM:
+            hipLaunchKernelGGL(k_stem<T>, dim3(blocks_for((long long)op.out_h * op.out_w)), dim3(kThreads), 0, s,
+                               static_cast<const unsigned char*>(op.in), op.in_h, op.in_w, w, op.bias, out, op.out_h, op.out_w,
+                               op.out_ld);
+            break;
+        case AVL_OP_MAXPOOL:
+            hipLaunchKernelGGL(k_maxpool<T>, dim3(blocks_for((long long)op.out_h * op.out_w * (op.in_c / 8))), dim3(kThreads), 0, s,
+                               in, op.in_h, op.in_w, op.in_c, op.in_ld, out, op.out_h, op.out_w, op.out_ld);
+            break;
+        case AVL_OP_GCONV: {
+            const int cg = op.in_c / op.groups;
+            const dim3 grid(blocks_for((long long)op.out_h * op.out_w), op.groups);
+#define AVL_GCONV(CG)                                                                                                   \
+    hipLaunchKernelGGL((k_gconv<T, CG>), grid, dim3(kThreads), 0, s, in, op.in_h, op.in_w, op.in_ld, w, op.bias, out, \
+                       op.out_h, op.out_w, op.out_ld, op.stride, op.dil)
+            if (cg == 4) AVL_GCONV(4);
+            else if (cg == 8) AVL_GCONV(8);
+            else if (cg == 16) AVL_GCONV(16);
+            else if (cg == 32) AVL_GCONV(32);
+            else if (cg == 2) AVL_GCONV(2);
+            else return set_error(AVL_E_UNSUPPORTED, "grouped conv with %d channels per group", cg);
+#undef AVL_GCONV
+            break;
+        }
+        case AVL_OP_DWCONV:
+            hipLaunchKernelGGL(k_dwconv<T>, dim3(blocks_for((long long)op.out_h * op.out_w * (op.in_c / 8))), dim3(kThreads), 0, s,
+                               in, op.in_h, op.in_w, op.in_c, op.in_ld, w, op.bias, out, op.out_h, op.out_w, op.out_ld, op.pad,
+                               op.dil, op.relu);
+            break;
+        case AVL_OP_BILINEAR:
+            hipLaunchKernelGGL(k_bilinear<T>, dim3(blocks_for((long long)op.out_h * op.out_w * (op.in_c / 8))), dim3(kThreads), 0, s,
+                               in, op.in_h, op.in_w, op.in_c, op.in_ld, out, op.out_h, op.out_w, op.out_ld);
+            break;
+        case AVL_OP_GAP: {
+            const int G = 256;
+            float* partial = static_cast<float*>(const_cast<void*>(op.in2));
+            hipLaunchKernelGGL(k_gap_partial<T>, dim3(G), dim3(kThreads), 0, s, in, op.in_h * op.in_w, op.in_c, op.in_ld, partial);
+            AVL_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_gap_final, dim3(blocks_for(op.in_c)), dim3(kThreads), 0, s, partial, G, op.in_c,
+                               op.in_h * op.in_w, static_cast<float*>(op.out));
+            break;
+        }
+        case AVL_OP_SUBSAMPLE:
+            hipLaunchKernelGGL(k_subsample<T>, dim3(blocks_for((long long)op.out_h * op.out_w * (op.in_c / 8))), dim3(kThreads), 0, s,
+                               in, op.in_w, op.in_c, op.in_ld, out, op.out_h, op.out_w, op.out_ld, op.stride);
+            break;
+        default:
+            return set_error(AVL_E_ARG, "op kind %d is not a typed conv op", op.kind);
+    }
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+}  // namespace
+
+int validate_conv_op(const avl_seg_op& op) {
+    const int es = elem_size(op.dtype);
+    AVL_REQUIRE(op.in && op.out, "op %d has NULL in/out", op.kind);
+    AVL_REQUIRE(op.in_h > 0 && op.in_w > 0 && op.out_h > 0 && op.out_w > 0, "op %d has empty spatial dims", op.kind);
+    const long long in_pix = (long long)op.in_h * op.in_w, out_pix = (long long)op.out_h * op.out_w;
+    switch (op.kind) {
+        case AVL_OP_STEM:
+            AVL_REQUIRE(op.weight && op.bias && op.out_c == 64 && op.in_c == 3, "stem expects 3 -> 64 channels");
+            AVL_REQUIRE(op.out_h == (op.in_h + 6 - 7) / 2 + 1 && op.out_w == (op.in_w + 6 - 7) / 2 + 1, "stem output size");
+            AVL_REQUIRE(op.out_rows >= out_pix && op.out_ld >= 64 && (op.out_ld * es) % 16 == 0, "stem output buffer");
+            return AVL_OK;
+        case AVL_OP_GEMV:
+            AVL_REQUIRE(op.weight && op.in_c > 0 && op.out_c > 0, "gemv shapes");
+            return AVL_OK;
+        case AVL_OP_ARGMAX:
+            AVL_REQUIRE(op.in_c > 0 && op.in_c <= 256 && op.in_ld >= op.in_c && op.in_rows >= in_pix && op.out_rows >= in_pix, "argmax shapes");
+            return AVL_OK;
+        case AVL_OP_GAP:
+            AVL_REQUIRE(op.in2 && op.in_c % 8 == 0 && op.in_rows >= in_pix && op.in_ld >= op.in_c, "gap shapes / scratch");
+            AVL_REQUIRE((op.in_ld * es) % 16 == 0, "gap in_ld");
+            return AVL_OK;
+        default:
+            break;
+    }
+    AVL_REQUIRE(op.dtype == AVL_BF16 || op.dtype == AVL_F32, "op %d dtype %d", op.kind, op.dtype);
+    AVL_REQUIRE(op.in_c % 8 == 0 || (op.kind == AVL_OP_GCONV), "op %d: channels %d not a multiple of 8", op.kind, op.in_c);
+    AVL_REQUIRE(op.in_rows >= in_pix && op.out_rows >= out_pix, "op %d: allocated rows too small", op.kind);
+    AVL_REQUIRE(op.in_ld >= op.in_c && op.out_ld >= op.out_c, "op %d: leading dims", op.kind);
+    AVL_REQUIRE((op.in_ld * es) % 16 == 0 && (op.out_ld * es) % 16 == 0, "op %d: row strides must be 16-byte multiples", op.kind);
+    AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.in) | reinterpret_cast<uintptr_t>(op.out)) % 16 == 0, "op %d: unaligned buffers", op.kind);
+    switch (op.kind) {
+        case AVL_OP_MAXPOOL:
+            AVL_REQUIRE(op.out_c == op.in_c && op.out_h == (op.in_h + 2 - 3) / 2 + 1 && op.out_w == (op.in_w + 2 - 3) / 2 + 1, "maxpool shapes");
+            break;
+        case AVL_OP_GCONV: {
+            AVL_REQUIRE(op.weight && op.bias && op.groups > 0 && op.in_c % op.groups == 0 && op.out_c == op.in_c, "gconv channels");
+            AVL_REQUIRE(op.ksize == 3 && (op.stride == 1 || op.stride == 2) && op.dil >= 1 && op.pad == op.dil, "gconv geometry");
+            AVL_REQUIRE(op.out_h == (op.in_h + 2 * op.pad - 2 * op.dil - 1) / op.stride + 1 &&
+                        op.out_w == (op.in_w + 2 * op.pad - 2 * op.dil - 1) / op.stride + 1, "gconv output size");
+            break;
+        }
+        case AVL_OP_DWCONV:
+            AVL_REQUIRE(op.weight && op.bias && op.out_c == op.in_c && op.ksize == 3 && op.stride == 1 && op.dil >= 1 && op.pad >= 0, "dwconv geometry");
+            AVL_REQUIRE(op.out_h == op.in_h + 2 * op.pad - 2 * op.dil && op.out_w == op.in_w + 2 * op.pad - 2 * op.dil, "dwconv output size");
+            break;
+        case AVL_OP_BILINEAR:
+            AVL_REQUIRE(op.out_c == op.in_c, "bilinear channels");
+            break;
+        case AVL_OP_SUBSAMPLE:
+            AVL_REQUIRE(op.out_c == op.in_c && op.stride >= 1 && (op.out_h - 1) * op.stride < op.in_h && (op.out_w - 1) * op.stride < op.in_w, "subsample geometry");
+            break;
+        default:
+            return set_error(AVL_E_ARG, "unknown op kind %d", op.kind);
+    }
+    return AVL_OK;
+}
+
+int launch_conv_op(const avl_seg_op& op, hipStream_t s) {
+    if (op.kind == AVL_OP_GEMV) {
+        hipLaunchKernelGGL(k_gemv, dim3((op.out_c + 3) / 4), dim3(kThreads), 0, s, static_cast<const float*>(op.in),
+                           static_cast<const float*>(op.weight), op.bias, static_cast<float*>(op.out), op.out_c, op.in_c, op.relu);
+        AVL_LAUNCH_CHECK();
+        return AVL_OK;
+    }
+    if (op.kind == AVL_OP_ARGMAX) {
+        const int M = op.in_h * op.in_w;
+        hipLaunchKernelGGL(k_argmax, dim3(blocks_for(M)), dim3(kThreads), 0, s, static_cast<const float*>(op.in), M, op.in_c,
+                           op.in_ld, static_cast<unsigned char*>(op.out));
+        AVL_LAUNCH_CHECK();
+        return AVL_OK;
+    }
+    if (op.dtype == AVL_BF16) return launch_typed<bf16>(op, s);
+    return launch_typed<float>(op, s);
+}
+
+}  // namespace avl

@@ -1,0 +1,270 @@
+// 1x1 convolution = GEMM on the matrix cores (gfx950).
+//
+//   out[m][n] = act( sum_k in[m][k] * w[n][k] + bias[n] (+ res[m][n]) )
+//
+// in  : NHWC activations, one row per pixel (row stride lda), K = input channels contiguous
+// w   : [n][k] (PyTorch's [Cout][Cin] with BatchNorm folded in), K contiguous
+// 94 % of the network's MACs run here, so this is the MFMA-bound kernel.
+//
+// Structure (one workgroup = WM x WN waves, each wave a 64 x 64 output tile, BK = 128 bytes of K):
+//   * both operand tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging), two LDS
+//     buffers, the load of K-step t+1 in flight while step t is multiplied; one barrier per step;
+//   * LDS rows are 128 B; the 16-byte chunk index is XOR-ed with (row & 7).  The DMA writes LDS
+//     linearly, so the swizzle is applied to the per-lane SOURCE address and again on the read;
+//   * the product is computed transposed (D^T = W . in^T): the MFMA "A" operand is the weight
+//     fragment, "B" the activation fragment, so a lane ends up holding 16 CONSECUTIVE channels of one
+//     pixel (weight rows are permuted inside the 64-wide wave tile to make that so) and the NHWC
+//     store / residual load are 32-byte (bf16) or 64-byte (fp32) contiguous per lane;
+//   * workgroup ids are remapped so that the tiles sharing an activation panel run on one XCD (L2).
+//   * T = bf16 : v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+//     T = float: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) -- the reference-precision mode.
+#include "seg_types.h"
+
+namespace avl {
+namespace {
+
+struct GemmArgs {
+    const void* A;
+    const void* W;
+    const float* bias;
+    const void* R;
+    void* C;
+    int lda, ldr, ldc;
+    int M, N, K;
+    int relu, out_f32;
+    int ntiles;
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <typename T, int WM, int WN>
+__global__ void __launch_bounds__(WM* WN * 64) k_gemm(GemmArgs p) {
+    constexpr int NW = WM * WN, BM = WM * 64, BN = WN * 64;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
+    constexpr int A_INSTR = BM / 8 / NW, W_INSTR = BN / 8 / NW;
+    static_assert(A_INSTR >= 1 && W_INSTR >= 1, "tile too small for the wave count");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware, bijective remap: workgroups b and b+8 share an XCD (and its L2); give each XCD a
+    // contiguous run of logical tiles so the WN.. tiles of one activation panel hit the same L2.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, local = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int nt = bid % p.ntiles, mt = bid / p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // per-lane DMA sources: lane -> (row = lane>>3 of an 8-row group, physical chunk = lane&7)
+    const char* a_src[A_INSTR];
+    const char* w_src[W_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int r = (i * NW + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (r & 7);
+        a_src[i] = static_cast<const char*>(p.A) + (long long)(m0 + r) * p.lda * (int)sizeof(T) + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < W_INSTR; ++i) {
+        const int r = (i * NW + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (r & 7);
+        w_src[i] = static_cast<const char*>(p.W) + (long long)(n0 + r) * p.K * (int)sizeof(T) + c * 16;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = lds + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) glds16(a_src[i] + (long long)kt * 128, base + (i * NW + wave) * 1024);
+#pragma unroll
+        for (int i = 0; i < W_INSTR; ++i) glds16(w_src[i] + (long long)kt * 128, base + A_BYTES + (i * NW + wave) * 1024);
+    };
+
+    // fragment addresses (constant over the K loop)
+    const int fr = lane & 15, kq = lane >> 4;
+    int a_row[4], w_row[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) a_row[mi] = wm * 64 + mi * 16 + fr;
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) w_row[nj] = wn * 64 + (fr >> 2) * 16 + nj * 4 + (fr & 3);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K * (int)sizeof(T) / 128;
+    stage(0, 0);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt has landed
+        __syncthreads();                                     // everyone's has; buffer cur^1 is free again
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* ab = lds + cur * BUF;
+        const char* wb = ab + A_BYTES;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int chunk = kk * 4 + kq;
+                bf16x8 af[4], wf[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    af[mi] = *reinterpret_cast<const bf16x8*>(ab + a_row[mi] * 128 + ((chunk ^ (a_row[mi] & 7)) << 4));
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj)
+                    wf[nj] = *reinterpret_cast<const bf16x8*>(wb + w_row[nj] * 128 + ((chunk ^ (w_row[nj] & 7)) << 4));
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < 4; ++nj)
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nj], af[mi], acc[mi][nj], 0, 0, 0);
+            }
+        } else {
+            // fp32: lane kq owns k = 8*kq .. 8*kq+7 of the 32-wide step; MFMA step s sums k-set {s, 8+s, 16+s, 24+s}
+            f32x4 af[4][2], wf[4][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int chunk = kq * 2 + h;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    af[mi][h] = *reinterpret_cast<const f32x4*>(ab + a_row[mi] * 128 + ((chunk ^ (a_row[mi] & 7)) << 4));
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj)
+                    wf[nj][h] = *reinterpret_cast<const f32x4*>(wb + w_row[nj] * 128 + ((chunk ^ (w_row[nj] & 7)) << 4));
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < 4; ++nj)
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nj][s >> 2][s & 3], af[mi][s >> 2][s & 3],
+                                                                           acc[mi][nj], 0, 0, 0);
+        }
+        cur ^= 1;
+    }
+
+    // epilogue: lane = (pixel fr of each 16-pixel sub-tile, channel block kq): 16 consecutive channels
+    const int nbase = n0 + wn * 64 + kq * 16;
+    float bias[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + nbase + 4 * j);
+        bias[4 * j] = b.x; bias[4 * j + 1] = b.y; bias[4 * j + 2] = b.z; bias[4 * j + 3] = b.w;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + fr;
+        if (m >= p.M || nbase >= p.N) continue;
+        float v[16];
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[nj * 4 + r] = acc[mi][nj][r] + bias[nj * 4 + r];
+        const bool full = nbase + 16 <= p.N;
+        if (p.R) {
+            const T* rp = static_cast<const T*>(p.R) + (long long)m * p.ldr + nbase;
+            if (full) {
+                float r0[8], r1[8];
+                Vec8<T>::load(rp, r0);
+                Vec8<T>::load(rp + 8, r1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { v[i] += r0[i]; v[8 + i] += r1[i]; }
+            } else {
+                for (int i = 0; i < 16; ++i)
+                    if (nbase + i < p.N) v[i] += to_f32(rp[i]);
+            }
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if (p.out_f32) {
+            float* cp = static_cast<float*>(p.C) + (long long)m * p.ldc + nbase;
+            for (int i = 0; i < 16; ++i)
+                if (nbase + i < p.N) cp[i] = v[i];
+        } else {
+            T* cp = static_cast<T*>(p.C) + (long long)m * p.ldc + nbase;
+            if (full) {
+                float lo[8], hi[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { lo[i] = v[i]; hi[i] = v[8 + i]; }
+                Vec8<T>::store(cp, lo);
+                Vec8<T>::store(cp + 8, hi);
+            } else {
+                for (int i = 0; i < 16; ++i)
+                    if (nbase + i < p.N) cp[i] = from_f32<T>(v[i]);
+            }
+        }
+    }
+}
+
+template <typename T, int WM, int WN>
+int launch_cfg(const GemmArgs& a, int mtiles, hipStream_t s) {
+    constexpr int LDS = 2 * (WM * 64 + WN * 64) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<T, WM, WN>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm<T, WM, WN>), dim3(mtiles * a.ntiles), dim3(WM * WN * 64), LDS, s, a);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+struct TileCfg { int bm, bn; };
+inline TileCfg pick_tile(const avl_seg_op& op) {
+    if (op.out_c <= 64) return {256, 64};
+    return {128, 128};
+}
+
+}  // namespace
+
+int validate_gemm(const avl_seg_op& op) {
+    const int es = elem_size(op.dtype);
+    AVL_REQUIRE(op.dtype == AVL_BF16 || op.dtype == AVL_F32, "GEMM dtype %d", op.dtype);
+    AVL_REQUIRE(op.in && op.out && op.weight && op.bias, "GEMM has NULL buffers");
+    const int M = op.out_h * op.out_w, K = op.in_c, N = op.out_c;
+    AVL_REQUIRE(M > 0 && N > 0 && K > 0, "GEMM M/N/K = %d/%d/%d", M, N, K);
+    AVL_REQUIRE(op.in_h * op.in_w == M, "GEMM in/out pixel counts differ (%d vs %d)", op.in_h * op.in_w, M);
+    AVL_REQUIRE((K * es) % 128 == 0, "GEMM K = %d is not a multiple of %d", K, 128 / es);
+    AVL_REQUIRE(op.in_ld >= K && (op.in_ld * es) % 16 == 0, "GEMM in_ld %d", op.in_ld);
+    AVL_REQUIRE(op.out_ld >= N, "GEMM out_ld %d < N %d", op.out_ld, N);
+    const TileCfg t = pick_tile(op);
+    const int mtiles = (M + t.bm - 1) / t.bm, ntiles = (N + t.bn - 1) / t.bn;
+    AVL_REQUIRE(op.in_rows >= mtiles * t.bm, "GEMM reads %d rows, input has %d allocated", mtiles * t.bm, op.in_rows);
+    AVL_REQUIRE(op.w_rows >= ntiles * t.bn, "GEMM reads %d weight rows, %d allocated", ntiles * t.bn, op.w_rows);
+    AVL_REQUIRE(op.out_rows >= M, "GEMM writes %d rows, output has %d", M, op.out_rows);
+    if (!op.out_f32) AVL_REQUIRE((op.out_ld * es) % 16 == 0 && N % 16 == 0, "GEMM out_ld %d / N %d not 16-aligned", op.out_ld, N);
+    if (op.in2) AVL_REQUIRE(op.in2_ld >= N && (op.in2_ld * es) % 16 == 0, "GEMM residual ld %d", op.in2_ld);
+    AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.in) | reinterpret_cast<uintptr_t>(op.weight) | reinterpret_cast<uintptr_t>(op.out) |
+                 reinterpret_cast<uintptr_t>(op.bias) | reinterpret_cast<uintptr_t>(op.in2)) % 16 == 0,
+                "GEMM buffers must be 16-byte aligned");
+    return AVL_OK;
+}
+
+int launch_gemm(const avl_seg_op& op, hipStream_t s) {
+    GemmArgs a;
+    a.A = op.in; a.W = op.weight; a.bias = op.bias; a.R = op.in2; a.C = op.out;
+    a.lda = op.in_ld; a.ldr = op.in2_ld; a.ldc = op.out_ld;
+    a.M = op.out_h * op.out_w; a.N = op.out_c; a.K = op.in_c;
+    a.relu = op.relu; a.out_f32 = op.out_f32;
+    const TileCfg t = pick_tile(op);
+    const int mtiles = (a.M + t.bm - 1) / t.bm;
+    a.ntiles = (a.N + t.bn - 1) / t.bn;
+    if (op.dtype == AVL_BF16) {
+        if (t.bn == 64) return launch_cfg<bf16, 4, 1>(a, mtiles, s);
+        return launch_cfg<bf16, 2, 2>(a, mtiles, s);
+    }
+    if (t.bn == 64) return launch_cfg<float, 4, 1>(a, mtiles, s);
+    return launch_cfg<float, 2, 2>(a, mtiles, s);
+}
+
+}  // namespace avl

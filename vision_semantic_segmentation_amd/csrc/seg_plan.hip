@@ -1,0 +1,129 @@
+// Segmentation plan: a validated, flat list of ops launched in order on one stream.
+#include <vector>
+
+#include "seg_types.h"
+
+struct avl_seg_plan {
+    std::vector<avl_seg_op> ops;
+    std::vector<hipEvent_t> ev;   // 2 per op, created lazily by avl_seg_plan_profile
+};
+
+namespace avl {
+namespace {
+
+int validate(const avl_seg_op& op, int index) {
+    int rc;
+    if (op.kind == AVL_OP_GEMM) rc = validate_gemm(op);
+    else rc = validate_conv_op(op);
+    if (rc != AVL_OK) {
+        char msg[400];
+        snprintf(msg, sizeof(msg), "%s", err_buf());
+        return set_error(rc, "op %d (kind %d): %s", index, op.kind, msg);
+    }
+    return AVL_OK;
+}
+
+int launch(const avl_seg_op& op, hipStream_t s) {
+    if (op.kind == AVL_OP_GEMM) return launch_gemm(op, s);
+    return launch_conv_op(op, s);
+}
+
+// algorithmic work of one op: flops (2 per MAC) and bytes (each tensor touched once)
+void work(const avl_seg_op& op, double& flops, double& bytes) {
+    const double es = elem_size(op.dtype);
+    const double in_pix = (double)op.in_h * op.in_w, out_pix = (double)op.out_h * op.out_w;
+    flops = 0;
+    bytes = in_pix * op.in_c * es + out_pix * op.out_c * es;
+    switch (op.kind) {
+        case AVL_OP_STEM:
+            flops = 2.0 * out_pix * 64 * 147;
+            bytes = in_pix * 3 + out_pix * 64 * es;
+            break;
+        case AVL_OP_GEMM:
+            flops = 2.0 * out_pix * op.out_c * op.in_c;
+            bytes += (double)op.out_c * op.in_c * es + (op.in2 ? out_pix * op.out_c * es : 0.0);
+            if (op.out_f32) bytes += out_pix * op.out_c * (4 - es);
+            break;
+        case AVL_OP_GCONV:
+            flops = 2.0 * out_pix * op.out_c * (op.in_c / op.groups) * 9;
+            break;
+        case AVL_OP_DWCONV:
+            flops = 2.0 * out_pix * op.out_c * 9;
+            break;
+        case AVL_OP_BILINEAR:
+            flops = 8.0 * out_pix * op.out_c;
+            break;
+        case AVL_OP_GAP:
+            flops = in_pix * op.in_c;
+            bytes = in_pix * op.in_c * es;
+            break;
+        case AVL_OP_GEMV:
+            flops = 2.0 * op.in_c * op.out_c;
+            bytes = 4.0 * op.in_c * op.out_c;
+            break;
+        case AVL_OP_ARGMAX:
+            bytes = in_pix * op.in_c * 4 + in_pix;
+            break;
+        default:
+            break;
+    }
+}
+
+}  // namespace
+}  // namespace avl
+
+extern "C" int avl_seg_plan_create(const avl_seg_op* ops_host, int n_ops, avl_seg_plan** out_plan) {
+    AVL_REQUIRE(ops_host && n_ops > 0 && out_plan, "avl_seg_plan_create: bad arguments");
+    for (int i = 0; i < n_ops; ++i) {
+        int rc = avl::validate(ops_host[i], i);
+        if (rc) return rc;
+    }
+    avl_seg_plan* p = new avl_seg_plan();
+    p->ops.assign(ops_host, ops_host + n_ops);
+    *out_plan = p;
+    return AVL_OK;
+}
+
+extern "C" void avl_seg_plan_destroy(avl_seg_plan* plan) {
+    if (!plan) return;
+    for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
+    delete plan;
+}
+
+extern "C" int avl_seg_plan_num_ops(const avl_seg_plan* plan) { return plan ? (int)plan->ops.size() : 0; }
+
+extern "C" int avl_seg_plan_run(avl_seg_plan* plan, void* stream) {
+    AVL_REQUIRE(plan, "plan is NULL");
+    hipStream_t s = avl::as_stream(stream);
+    for (const avl_seg_op& op : plan->ops) {
+        int rc = avl::launch(op, s);
+        if (rc) return rc;
+    }
+    return AVL_OK;
+}
+
+extern "C" int avl_seg_plan_profile(avl_seg_plan* plan, void* stream, float* ms_host, double* flops_host, double* bytes_host) {
+    AVL_REQUIRE(plan && ms_host, "avl_seg_plan_profile: bad arguments");
+    hipStream_t s = avl::as_stream(stream);
+    const size_t n = plan->ops.size();
+    while (plan->ev.size() < 2 * n) {
+        hipEvent_t e;
+        AVL_HIP_CHECK(hipEventCreate(&e));
+        plan->ev.push_back(e);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        AVL_HIP_CHECK(hipEventRecord(plan->ev[2 * i], s));
+        int rc = avl::launch(plan->ops[i], s);
+        if (rc) return rc;
+        AVL_HIP_CHECK(hipEventRecord(plan->ev[2 * i + 1], s));
+    }
+    AVL_HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < n; ++i) {
+        AVL_HIP_CHECK(hipEventElapsedTime(&ms_host[i], plan->ev[2 * i], plan->ev[2 * i + 1]));
+        double f, b;
+        avl::work(plan->ops[i], f, b);
+        if (flops_host) flops_host[i] = f;
+        if (bytes_host) bytes_host[i] = b;
+    }
+    return AVL_OK;
+}

@@ -1,0 +1,60 @@
+// Element-type helpers shared by the segmentation kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "avl_common.h"
+
+namespace avl {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+// 8 consecutive activation elements <-> 8 floats
+template <typename T>
+struct Vec8;
+
+template <>
+struct Vec8<bf16> {
+    static __device__ __forceinline__ void load(const bf16* p, float (&v)[8]) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)x[i];
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float (&v)[8]) {
+        bf16x8 x;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = (bf16)v[i];   // v_cvt_pk_bf16_f32: round to nearest even
+        *reinterpret_cast<bf16x8*>(p) = x;
+    }
+};
+
+template <>
+struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+inline int elem_size(int dtype) { return dtype == AVL_F32 ? 4 : 2; }
+
+// launchers implemented in seg_gemm.hip / seg_conv.hip; each validates its op and returns AVL_*
+int launch_gemm(const avl_seg_op& op, hipStream_t s);
+int validate_gemm(const avl_seg_op& op);
+int launch_conv_op(const avl_seg_op& op, hipStream_t s);
+int validate_conv_op(const avl_seg_op& op);
+
+}  // namespace avl

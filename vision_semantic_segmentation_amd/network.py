@@ -1,0 +1,465 @@
+"""DeepLabV3+ / ResNeXt-50 (output stride 8) as a flat program for libavl_hip.so.
+
+The reference assembles the model from torch modules:
+  backbone  torchvision ResNet(Bottleneck,[3,4,6,3], groups=32, width_per_group=4,
+            replace_stride_with_dilation=(False,True,True))      backbone/resnet.py:8-43, build.py:14-20
+  ASPP      1x1 | 3 x (depthwise 3x3 d=12/24/36 + 1x1) | image pooling ; concat ; 1x1       aspp.py:16-95
+  decoder   1x1 on layer1 ; bilinear x2 ; concat ; 2 x (depthwise 3x3 pad 0 + 1x1) ; 1x1    decoder.py:10-51
+This module keeps the reference's checkpoint format (``{'model': state_dict}`` with ``module.``
+prefixed keys, core/utils/checkpoint.py:52) and turns a state dict into what the HIP kernels eat:
+BatchNorm folded into the preceding convolution (eval mode, eps 1e-5), NHWC activations, 1x1
+weights as [Cout][Cin] rows padded to the GEMM tile, grouped / depthwise / stem weights re-laid for
+their kernels, and a list of ``avl_seg_op`` records.
+
+Two graph-level rewrites, both exact in real arithmetic:
+  * torch.cat is free: producers write into channel slices of one wide buffer (out_ld);
+  * the image-pooling branch is constant over the image after its bilinear "upsample" of a 1x1 map
+    (aspp.py:86-89), so its share of the 1280->256 projection is a per-channel constant:
+    it becomes a bias vector computed per frame by two small GEMVs.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+BN_EPS = 1e-5
+
+OP_STEM, OP_MAXPOOL, OP_GEMM, OP_GCONV, OP_DWCONV, OP_BILINEAR, OP_GAP, OP_GEMV, OP_ARGMAX, OP_SUBSAMPLE = range(1, 11)
+OP_NAMES = {1: "stem", 2: "maxpool", 3: "gemm", 4: "gconv", 5: "dwconv", 6: "bilinear", 7: "gap", 8: "gemv", 9: "argmax", 10: "subsample"}
+
+
+class AvlSegOp(C.Structure):
+    """struct avl_seg_op of include/avl_hip.h"""
+    _fields_ = [
+        ("kind", C.c_int32), ("dtype", C.c_int32),
+        ("in_", C.c_void_p), ("in2", C.c_void_p), ("out", C.c_void_p), ("weight", C.c_void_p), ("bias", C.c_void_p),
+        ("in_h", C.c_int32), ("in_w", C.c_int32), ("in_c", C.c_int32), ("in_ld", C.c_int32), ("in_rows", C.c_int32),
+        ("out_h", C.c_int32), ("out_w", C.c_int32), ("out_c", C.c_int32), ("out_ld", C.c_int32), ("out_rows", C.c_int32),
+        ("in2_ld", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32), ("groups", C.c_int32),
+        ("relu", C.c_int32), ("out_f32", C.c_int32), ("w_rows", C.c_int32), ("reserved", C.c_int32 * 3),
+    ]
+
+
+_vp, _i = C.c_void_p, C.c_int
+_lib._register_seg({
+    "avl_seg_plan_create": (_i, [C.POINTER(AvlSegOp), _i, C.POINTER(C.c_void_p)]),
+    "avl_seg_plan_destroy": (None, [_vp]),
+    "avl_seg_plan_run": (_i, [_vp, _vp]),
+    "avl_seg_plan_profile": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "avl_seg_plan_num_ops": (_i, [_vp]),
+})
+
+# ----------------------------------------------------------------------------------------------
+# state dict: names and shapes of the reference checkpoint
+# ----------------------------------------------------------------------------------------------
+
+LAYERS = (3, 4, 6, 3)
+PLANES = (64, 128, 256, 512)
+GROUPS, WIDTH_PER_GROUP, EXPANSION = 32, 4, 4
+
+
+def _bn_keys(prefix, c):
+    return [(prefix + ".weight", (c,)), (prefix + ".bias", (c,)), (prefix + ".running_mean", (c,)),
+            (prefix + ".running_var", (c,))]
+
+
+def state_spec(num_classes=19, in_channels=3, aspp_out=256, atrous_channels=(256, 256, 256, 256), low_level_out=256,
+               refine_channels=(256, 256)):
+    """[(key, shape)] of DeepLabV3Plus.state_dict() for MODEL.BACKBONE = resnext50_32x4d (keys as
+    saved by the reference, without the DataParallel 'module.' prefix)."""
+    spec = [("backbone.conv1.weight", (64, in_channels, 7, 7))] + _bn_keys("backbone.bn1", 64)
+    inplanes = 64
+    for li, (planes, nblocks) in enumerate(zip(PLANES, LAYERS), start=1):
+        width = int(planes * (WIDTH_PER_GROUP / 64.0)) * GROUPS
+        for b in range(nblocks):
+            p = "backbone.layer%d.%d" % (li, b)
+            spec += [(p + ".conv1.weight", (width, inplanes, 1, 1))] + _bn_keys(p + ".bn1", width)
+            spec += [(p + ".conv2.weight", (width, width // GROUPS, 3, 3))] + _bn_keys(p + ".bn2", width)
+            spec += [(p + ".conv3.weight", (planes * EXPANSION, width, 1, 1))] + _bn_keys(p + ".bn3", planes * EXPANSION)
+            if b == 0:
+                spec += [(p + ".downsample.0.weight", (planes * EXPANSION, inplanes, 1, 1))] + _bn_keys(p + ".downsample.1", planes * EXPANSION)
+            inplanes = planes * EXPANSION
+    feat, low = inplanes, PLANES[0] * EXPANSION
+    spec += [("aspp.module_pyramid.0.conv.weight", (atrous_channels[0], feat, 1, 1))] + _bn_keys("aspp.module_pyramid.0.bn", atrous_channels[0])
+    for i in range(1, len(atrous_channels)):
+        p = "aspp.module_pyramid.%d" % i
+        spec += [(p + ".depthwise_cnn.conv.weight", (feat, 1, 3, 3))] + _bn_keys(p + ".depthwise_cnn.bn", feat)
+        spec += [(p + ".pointwise_cnn.conv.weight", (atrous_channels[i], feat, 1, 1))] + _bn_keys(p + ".pointwise_cnn.bn", atrous_channels[i])
+    spec += [("aspp.global_avg_pool.1.conv.weight", (256, feat, 1, 1))] + _bn_keys("aspp.global_avg_pool.1.bn", 256)
+    spec += [("aspp.conv.conv.weight", (aspp_out, sum(atrous_channels) + 256, 1, 1))] + _bn_keys("aspp.conv.bn", aspp_out)
+    spec += [("decoder.low_level_conv.conv.weight", (low_level_out, low, 1, 1))] + _bn_keys("decoder.low_level_conv.bn", low_level_out)
+    cin = low_level_out + aspp_out
+    for i, rc in enumerate(refine_channels):
+        p = "decoder.refine_layers.%d" % i
+        spec += [(p + ".depthwise_cnn.conv.weight", (cin, 1, 3, 3))] + _bn_keys(p + ".depthwise_cnn.bn", cin)
+        spec += [(p + ".pointwise_cnn.conv.weight", (rc, cin, 1, 1))] + _bn_keys(p + ".pointwise_cnn.bn", rc)
+        cin = rc
+    p = "decoder.refine_layers.%d" % len(refine_channels)
+    spec += [(p + ".conv.weight", (num_classes, cin, 1, 1)), (p + ".conv.bias", (num_classes,))]
+    return spec
+
+
+def random_state_dict(seed=0, **kw):
+    """Seeded random weights of the right shapes (there are no trained weights offline): Kaiming-normal
+    convolutions, and NON-trivial BatchNorm statistics so that folding is exercised.  The gains are
+    chosen so activations keep O(1) scale through all 50+ layers."""
+    g = torch.Generator().manual_seed(seed)
+    st = {}
+    for key, shape in state_spec(**kw):
+        if key.endswith("running_var"):
+            t = torch.rand(shape, generator=g) * 0.5 + 0.75
+        elif key.endswith("running_mean"):
+            t = torch.randn(shape, generator=g) * 0.1
+        elif key.endswith(".weight") and len(shape) == 1:
+            t = torch.rand(shape, generator=g) * 0.4 + 0.8
+            if ".bn3." in key or "downsample.1" in key:
+                t = t * 0.6          # keep the residual sum from growing block after block
+        elif key.endswith(".bias"):
+            t = torch.randn(shape, generator=g) * 0.05
+        else:
+            fan_in = shape[1] * shape[2] * shape[3]
+            t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+        st[key] = t.to(torch.float32)
+    return st
+
+
+def load_checkpoint(path):
+    """semantic_segmentation.py:31-32: torch.load(...).pop('model'); keys carry 'module.' (DataParallel).
+    Loaded with weights_only=True -- nothing in the file is executed."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    state = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
+    return {(k[7:] if k.startswith("module.") else k): v.to(torch.float32) for k, v in state.items()
+            if not k.endswith("num_batches_tracked")}
+
+
+def check_state_dict(state, **kw):
+    missing = [k for k, s in state_spec(**kw) if k not in state or tuple(state[k].shape) != tuple(s)]
+    if missing:
+        raise KeyError("state dict lacks / mis-shapes %d tensors, e.g. %s" % (len(missing), missing[:3]))
+
+
+# ----------------------------------------------------------------------------------------------
+# folding + packing
+# ----------------------------------------------------------------------------------------------
+
+def fold_bn(state, conv_key, bn_prefix):
+    """conv -> BN(eval) == conv with w*s and bias b - mean*s, s = gamma/sqrt(var+eps).  float64 on the host."""
+    w = state[conv_key].to(torch.float64)
+    if bn_prefix is None:
+        b = state.get(conv_key[:-6] + "bias")
+        return w, (b.to(torch.float64) if b is not None else torch.zeros(w.shape[0], dtype=torch.float64))
+    s = state[bn_prefix + ".weight"].to(torch.float64) / torch.sqrt(state[bn_prefix + ".running_var"].to(torch.float64) + BN_EPS)
+    b = state[bn_prefix + ".bias"].to(torch.float64) - state[bn_prefix + ".running_mean"].to(torch.float64) * s
+    return w * s.view(-1, 1, 1, 1), b
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class SegNet(object):
+    """The compiled network for one input size and precision: device buffers, packed weights and the
+    native plan.  ``forward(image_u8_cuda)`` runs it; ``labels`` / ``logits`` are views of its outputs."""
+
+    ROW_PAD = 256        # GEMM tiles read whole 128/256-row tiles
+
+    def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8):
+        assert output_stride == 8, "the reference configuration is OS8 (base_cfg.py:106)"
+        assert precision in ("bf16", "f32")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.H, self.W = int(height), int(width)
+        self.precision = precision
+        self.act_dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.avl_dtype = _lib.AVL_BF16 if precision == "bf16" else _lib.AVL_F32
+        self.num_classes = num_classes
+        self._keep = []            # every tensor the plan points at
+        self._free = {}            # numel -> [tensor] pool of released activation buffers
+        self.ops = []
+        self.op_names = []
+        self._plan = C.c_void_p()
+        self._build(state)
+        arr = (AvlSegOp * len(self.ops))(*self.ops)
+        _lib.check(_lib.lib().avl_seg_plan_create(arr, len(self.ops), C.byref(self._plan)), "avl_seg_plan_create")
+
+    def __del__(self):
+        try:
+            if self._plan:
+                _lib.lib().avl_seg_plan_destroy(self._plan)
+        except Exception:
+            pass
+
+    # -------------------------------------------------------------------------------- buffers
+    def _act(self, rows, ch):
+        """activation buffer [rows padded][ch]"""
+        prow = _round_up(rows, self.ROW_PAD)
+        key = (prow, ch)
+        if self._free.get(key):
+            return self._free[key].pop()
+        t = torch.zeros((prow, ch), dtype=self.act_dtype, device=self.device)
+        self._keep.append(t)
+        return t
+
+    def _release(self, t):
+        self._free.setdefault((t.shape[0], t.shape[1]), []).append(t)
+
+    def _dev(self, t, dtype):
+        t = t.to(dtype).contiguous().to(self.device)
+        self._keep.append(t)
+        return t
+
+    # -------------------------------------------------------------------------------- op emitters
+    def _op(self, name, kind, **f):
+        op = AvlSegOp()
+        op.kind = kind
+        op.dtype = self.avl_dtype
+        for k, v in f.items():
+            setattr(op, k, v)
+        self.ops.append(op)
+        self.op_names.append(name)
+
+    @staticmethod
+    def _view(t, col=0):
+        """(pointer to column `col` of a [rows][ld] buffer, ld, rows)"""
+        return t.data_ptr() + col * t.element_size(), t.shape[1], t.shape[0]
+
+    def _gemm(self, name, src, hw, cin, w, b, dst, dst_col=0, relu=True, res=None, out_f32=False, src_col=0, bias_dev=None):
+        """1x1 conv.  w float64 [cout][cin] (BN folded), b float64 [cout]."""
+        h, wd = hw
+        cout = w.shape[0]
+        w_rows = _round_up(cout, 128)
+        wp = torch.zeros((w_rows, cin), dtype=torch.float64)
+        wp[:cout] = w.reshape(cout, cin)
+        wdev = self._dev(wp, self.act_dtype)
+        if bias_dev is None:
+            bp = torch.zeros(w_rows, dtype=torch.float64)
+            bp[:cout] = b
+            bias_dev = self._dev(bp, torch.float32)
+        ip, ild, irows = self._view(src, src_col)
+        op_, old, orows = self._view(dst, dst_col)
+        f = dict(in_=ip, out=op_, weight=wdev.data_ptr(), bias=bias_dev.data_ptr(), in_h=h, in_w=wd, in_c=cin, in_ld=ild,
+                 in_rows=irows, out_h=h, out_w=wd, out_c=cout, out_ld=old, out_rows=orows, relu=int(relu), out_f32=int(out_f32),
+                 w_rows=w_rows, ksize=1, stride=1, dil=1, groups=1)
+        if res is not None:
+            rp, rld, _ = self._view(res)
+            f.update(in2=rp, in2_ld=rld)
+        self._op(name, OP_GEMM, **f)
+
+    def _spatial(self, name, kind, src, in_hw, cin, dst, out_hw, cout, weight=None, bias=None, dst_col=0, **extra):
+        ip, ild, irows = self._view(src)
+        op_, old, orows = self._view(dst, dst_col)
+        f = dict(in_=ip, out=op_, in_h=in_hw[0], in_w=in_hw[1], in_c=cin, in_ld=ild, in_rows=irows, out_h=out_hw[0],
+                 out_w=out_hw[1], out_c=cout, out_ld=old, out_rows=orows)
+        if weight is not None:
+            f["weight"] = weight.data_ptr()
+        if bias is not None:
+            f["bias"] = bias.data_ptr()
+        f.update(extra)
+        self._op(name, kind, **f)
+
+    # -------------------------------------------------------------------------------- the network
+    def _build(self, st):
+        H, W = self.H, self.W
+        dev = self.device
+        self.image = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+        self._keep.append(self.image)
+
+        # ---- stem: conv1 7x7 s2 + bn1 + relu (resnet.py:25-27), maxpool (:28)
+        h2, w2 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        w, b = fold_bn(st, "backbone.conv1.weight", "backbone.bn1")
+        w_stem = self._dev(w.permute(2, 3, 1, 0).reshape(-1), torch.float32)          # [ky][kx][ci][co]
+        b_stem = self._dev(b, torch.float32)
+        stem = self._act(h2 * w2, 64)
+        self._op("backbone.conv1", OP_STEM, in_=self.image.data_ptr(), out=stem.data_ptr(), weight=w_stem.data_ptr(),
+                 bias=b_stem.data_ptr(), in_h=H, in_w=W, in_c=3, in_ld=3, in_rows=H * W, out_h=h2, out_w=w2, out_c=64,
+                 out_ld=64, out_rows=stem.shape[0], ksize=7, stride=2, pad=3, dil=1, groups=1, relu=1)
+        h4, w4 = (h2 + 2 - 3) // 2 + 1, (w2 + 2 - 3) // 2 + 1
+        x = self._act(h4 * w4, 64)
+        self._spatial("backbone.maxpool", OP_MAXPOOL, stem, (h2, w2), 64, x, (h4, w4), 64, ksize=3, stride=2, pad=1, dil=1)
+        self._release(stem)
+
+        # ---- layer1..4 (torchvision _make_layer, replace_stride_with_dilation = (False, True, True))
+        hw, cin = (h4, w4), 64
+        dilation = 1
+        low = None
+        for li, (planes, nblocks, stride0, dilate) in enumerate(zip(PLANES, LAYERS, (1, 2, 2, 2), (False, False, True, True)), start=1):
+            width = int(planes * (WIDTH_PER_GROUP / 64.0)) * GROUPS
+            cout = planes * EXPANSION
+            previous_dilation = dilation
+            stride = stride0
+            if dilate:
+                dilation *= stride
+                stride = 1
+            for bi in range(nblocks):
+                p = "backbone.layer%d.%d" % (li, bi)
+                s = stride if bi == 0 else 1
+                d = previous_dilation if bi == 0 else dilation
+                ohw = ((hw[0] + 2 * d - 2 * d - 1) // s + 1, (hw[1] + 2 * d - 2 * d - 1) // s + 1)
+                # conv1 1x1 + bn1 + relu
+                w, b = fold_bn(st, p + ".conv1.weight", p + ".bn1")
+                t1 = self._act(hw[0] * hw[1], width)
+                self._gemm(p + ".conv1", x, hw, cin, w, b, t1)
+                # conv2 3x3 grouped + bn2 + relu
+                w, b = fold_bn(st, p + ".conv2.weight", p + ".bn2")
+                cg = width // GROUPS
+                wg = w.reshape(GROUPS, cg, cg, 3, 3).permute(0, 3, 4, 2, 1).reshape(-1)   # [g][ky][kx][ci][co]
+                wg_d, bg_d = self._dev(wg, torch.float32), self._dev(b, torch.float32)
+                t2 = self._act(ohw[0] * ohw[1], width)
+                self._spatial(p + ".conv2", OP_GCONV, t1, hw, width, t2, ohw, width, wg_d, bg_d, ksize=3, stride=s, pad=d, dil=d,
+                              groups=GROUPS, relu=1)
+                self._release(t1)
+                # identity / downsample
+                if (p + ".downsample.0.weight") in st:
+                    w, b = fold_bn(st, p + ".downsample.0.weight", p + ".downsample.1")
+                    src = x
+                    if s != 1:
+                        sub = self._act(ohw[0] * ohw[1], cin)
+                        self._spatial(p + ".downsample.sub", OP_SUBSAMPLE, x, hw, cin, sub, ohw, cin, stride=s)
+                        src = sub
+                    idn = self._act(ohw[0] * ohw[1], cout)
+                    self._gemm(p + ".downsample", src, ohw, cin, w, b, idn, relu=False)
+                    if s != 1:
+                        self._release(sub)
+                else:
+                    idn = x
+                # conv3 1x1 + bn3 + residual + relu
+                w, b = fold_bn(st, p + ".conv3.weight", p + ".bn3")
+                y = self._act(ohw[0] * ohw[1], cout)
+                self._gemm(p + ".conv3", t2, ohw, width, w, b, y, relu=True, res=idn)
+                self._release(t2)
+                if idn is not x:
+                    self._release(idn)
+                if x is not low:              # layer1's output stays alive for the decoder
+                    self._release(x)
+                x, hw, cin = y, ohw, cout
+            if li == 1:
+                low, low_hw, low_c = x, hw, cin           # low_features = layer1 output (resnet.py:33-34)
+
+        feat, fhw, fc = x, hw, cin
+        M = fhw[0] * fhw[1]
+
+        # ---- ASPP (aspp.py:79-95), dilations forced to 1,12,24,36 for OS8 (deeplab_v3_plus.py:33-34)
+        dil = (1, 12, 24, 36)
+        branches = []
+        i = 0
+        while ("aspp.module_pyramid.%d.conv.weight" % i) in st or ("aspp.module_pyramid.%d.depthwise_cnn.conv.weight" % i) in st:
+            branches.append(i)
+            i += 1
+        bch = [st["aspp.module_pyramid.0.conv.weight"].shape[0]] + [st["aspp.module_pyramid.%d.pointwise_cnn.conv.weight" % k].shape[0]
+                                                                    for k in branches[1:]]
+        ncat = sum(bch)
+        cat = self._act(M, ncat)
+        w, b = fold_bn(st, "aspp.module_pyramid.0.conv.weight", "aspp.module_pyramid.0.bn")
+        self._gemm("aspp.module_pyramid.0", feat, fhw, fc, w, b, cat, dst_col=0)
+        col = bch[0]
+        for k in branches[1:]:
+            p = "aspp.module_pyramid.%d" % k
+            w, b = fold_bn(st, p + ".depthwise_cnn.conv.weight", p + ".depthwise_cnn.bn")
+            wd_, bd_ = self._dev(w.reshape(fc, 9).t().reshape(-1), torch.float32), self._dev(b, torch.float32)    # [tap][C]
+            t = self._act(M, fc)
+            self._spatial(p + ".depthwise_cnn", OP_DWCONV, feat, fhw, fc, t, fhw, fc, wd_, bd_, ksize=3, stride=1, pad=dil[k],
+                          dil=dil[k], groups=fc, relu=1)
+            w, b = fold_bn(st, p + ".pointwise_cnn.conv.weight", p + ".pointwise_cnn.bn")
+            self._gemm(p + ".pointwise_cnn", t, fhw, fc, w, b, cat, dst_col=col)
+            self._release(t)
+            col += bch[k]
+        # image pooling branch -> per-frame bias of the projection
+        wg_, bg_ = fold_bn(st, "aspp.global_avg_pool.1.conv.weight", "aspp.global_avg_pool.1.bn")
+        wp_, bp_ = fold_bn(st, "aspp.conv.conv.weight", "aspp.conv.bn")
+        npool = wg_.shape[0]
+        aspp_out = wp_.shape[0]
+        wp_ = wp_.reshape(aspp_out, ncat + npool)
+        gap_partial = torch.zeros((256, fc), dtype=torch.float32, device=dev)
+        gap_vec = torch.zeros(fc, dtype=torch.float32, device=dev)
+        pool_vec = torch.zeros(npool, dtype=torch.float32, device=dev)
+        proj_bias = torch.zeros(_round_up(aspp_out, 128), dtype=torch.float32, device=dev)
+        self._keep += [gap_partial, gap_vec, pool_vec, proj_bias]
+        fp, fld, frows = self._view(feat)
+        self._op("aspp.global_avg_pool.0", OP_GAP, in_=fp, in2=gap_partial.data_ptr(), out=gap_vec.data_ptr(), in_h=fhw[0], in_w=fhw[1],
+                 in_c=fc, in_ld=fld, in_rows=frows, out_h=1, out_w=1, out_c=fc, out_ld=fc, out_rows=1)
+        wgd, bgd = self._dev(wg_.reshape(npool, fc), torch.float32), self._dev(bg_, torch.float32)
+        self._op("aspp.global_avg_pool.1", OP_GEMV, dtype=_lib.AVL_F32, in_=gap_vec.data_ptr(), out=pool_vec.data_ptr(), weight=wgd.data_ptr(),
+                 bias=bgd.data_ptr(), in_h=1, in_w=1, in_c=fc, in_ld=fc, in_rows=1, out_h=1, out_w=1, out_c=npool, out_ld=npool,
+                 out_rows=1, relu=1)
+        wpd, bpd = self._dev(wp_[:, ncat:], torch.float32), self._dev(bp_, torch.float32)
+        self._op("aspp.conv[pool slice]", OP_GEMV, dtype=_lib.AVL_F32, in_=pool_vec.data_ptr(), out=proj_bias.data_ptr(), weight=wpd.data_ptr(),
+                 bias=bpd.data_ptr(), in_h=1, in_w=1, in_c=npool, in_ld=npool, in_rows=1, out_h=1, out_w=1, out_c=aspp_out,
+                 out_ld=aspp_out, out_rows=1, relu=0)
+        aspp = self._act(M, aspp_out)
+        self._gemm("aspp.conv", cat, fhw, ncat, wp_[:, :ncat], None, aspp, bias_dev=proj_bias)       # dropout = identity (eval)
+        self._release(cat)
+        self._release(feat)
+
+        # ---- decoder (decoder.py:45-51)
+        w, b = fold_bn(st, "decoder.low_level_conv.conv.weight", "decoder.low_level_conv.bn")
+        low_out = w.shape[0]
+        Ml = low_hw[0] * low_hw[1]
+        cat2 = self._act(Ml, aspp_out + low_out)
+        self._gemm("decoder.low_level_conv", low, low_hw, low_c, w, b, cat2, dst_col=aspp_out)
+        self._spatial("decoder.interpolate", OP_BILINEAR, aspp, fhw, aspp_out, cat2, low_hw, aspp_out)
+        self._release(aspp)
+        self._release(low)
+        x, hw, cin = cat2, low_hw, aspp_out + low_out
+        k = 0
+        while ("decoder.refine_layers.%d.depthwise_cnn.conv.weight" % k) in st:
+            p = "decoder.refine_layers.%d" % k
+            ohw = (hw[0] - 2, hw[1] - 2)                                # padding 0 (decoder.py:33-36 default)
+            w, b = fold_bn(st, p + ".depthwise_cnn.conv.weight", p + ".depthwise_cnn.bn")
+            wd_, bd_ = self._dev(w.reshape(cin, 9).t().reshape(-1), torch.float32), self._dev(b, torch.float32)
+            t = self._act(ohw[0] * ohw[1], cin)
+            self._spatial(p + ".depthwise_cnn", OP_DWCONV, x, hw, cin, t, ohw, cin, wd_, bd_, ksize=3, stride=1, pad=0, dil=1, groups=cin, relu=1)
+            self._release(x)
+            w, b = fold_bn(st, p + ".pointwise_cnn.conv.weight", p + ".pointwise_cnn.bn")
+            y = self._act(ohw[0] * ohw[1], w.shape[0])
+            self._gemm(p + ".pointwise_cnn", t, ohw, cin, w, b, y)
+            self._release(t)
+            x, hw, cin = y, ohw, w.shape[0]
+            k += 1
+        p = "decoder.refine_layers.%d" % k
+        w, b = fold_bn(st, p + ".conv.weight", None)
+        self.out_h, self.out_w = hw
+        Mo = hw[0] * hw[1]
+        self.logits_buf = torch.zeros((_round_up(Mo, self.ROW_PAD), self.num_classes), dtype=torch.float32, device=dev)
+        self.labels_buf = torch.zeros(_round_up(Mo, self.ROW_PAD), dtype=torch.uint8, device=dev)
+        self._keep += [self.logits_buf, self.labels_buf]
+        self._gemm(p, x, hw, cin, w, b, self.logits_buf, relu=False, out_f32=True)
+        self._op("argmax", OP_ARGMAX, dtype=_lib.AVL_F32, in_=self.logits_buf.data_ptr(), out=self.labels_buf.data_ptr(), in_h=hw[0], in_w=hw[1],
+                 in_c=self.num_classes, in_ld=self.num_classes, in_rows=self.logits_buf.shape[0], out_h=hw[0], out_w=hw[1], out_c=1,
+                 out_ld=1, out_rows=self.labels_buf.shape[0])
+
+    # -------------------------------------------------------------------------------- running
+    @property
+    def labels(self):
+        """uint8 CUDA tensor [out_h, out_w] of the last forward (argmax over classes)."""
+        return self.labels_buf[:self.out_h * self.out_w].view(self.out_h, self.out_w)
+
+    @property
+    def logits(self):
+        """float32 CUDA tensor [out_h, out_w, K] of the last forward (NHWC)."""
+        return self.logits_buf[:self.out_h * self.out_w].view(self.out_h, self.out_w, self.num_classes)
+
+    def forward(self, image_u8=None, stream=None):
+        """image_u8: CUDA/CPU uint8 [H,W,3] RGB (copied into the plan's input buffer) or None to reuse it."""
+        if image_u8 is not None:
+            if not isinstance(image_u8, torch.Tensor):
+                image_u8 = torch.from_numpy(np.ascontiguousarray(image_u8))
+            assert tuple(image_u8.shape) == (self.H, self.W, 3) and image_u8.dtype == torch.uint8
+            self.image.copy_(image_u8, non_blocking=True)
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        _lib.check(_lib.lib().avl_seg_plan_run(self._plan, C.c_void_p(s)), "avl_seg_plan_run")
+        return self.labels
+
+    def profile(self):
+        """HIP-event time of every op (ms), plus its algorithmic flops and bytes -> list of dicts."""
+        n = len(self.ops)
+        ms, fl, by = (C.c_float * n)(), (C.c_double * n)(), (C.c_double * n)()
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().avl_seg_plan_profile(self._plan, C.c_void_p(s), ms, fl, by), "avl_seg_plan_profile")
+        return [dict(name=self.op_names[i], kind=OP_NAMES[self.ops[i].kind], ms=ms[i], flops=fl[i], bytes=by[i]) for i in range(n)]
+
+    def total_flops(self):
+        n = len(self.ops)
+        return sum(r["flops"] for r in self.profile()) if n else 0.0

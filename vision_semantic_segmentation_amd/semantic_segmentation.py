@@ -1,0 +1,96 @@
+"""SemanticSegmentation -- the reference's inference wrapper (src/semantic_segmentation.py:20-57)
+on the HIP conv stack.
+
+    seg = SemanticSegmentation(cfg.VISION_SEM_SEG.SEM_SEG_NETWORK)
+    labels = seg.segmentation(image_rgb_u8)        # int64 ndarray [h/4-4, w/4-4], as the reference returns
+
+Differences by design: weights come from a LOCAL checkpoint (``MODEL.WEIGHT``) in the reference's
+format or, when that is empty, from a seeded random init -- the reference's
+``resnext50_32x4d(pretrained=True)`` URL fetch (backbone/build.py:20) is never attempted;
+normalisation (ToTensor + Normalize, :35-39) is fused into the stem kernel; the arg-max runs on the
+GPU and ``segmentation_device`` hands back the uint8 label map without leaving HBM.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .network import SegNet, check_state_dict, load_checkpoint, random_state_dict
+
+
+class SemanticSegmentation(object):
+    def __init__(self, cfg, device=None, state_dict=None):
+        """cfg: network configuration (cfg.VISION_SEM_SEG.SEM_SEG_NETWORK of base_cfg.py:96-112)."""
+        _lib.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("SemanticSegmentation needs a GPU (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if cfg.MODEL.TYPE != "DeepLabv3+" or cfg.MODEL.BACKBONE != "resnext50_32x4d" or cfg.MODEL.OUTPUT_STRIDE != 8:
+            raise NotImplementedError("only the reference configuration (DeepLabv3+, resnext50_32x4d, OS8) is built")
+        self.cfg = cfg
+        self.num_classes = cfg.DATASET.NUM_CLASSES
+        self.precision = getattr(cfg.MODEL, "PRECISION", "bf16")
+        kw = dict(num_classes=self.num_classes, in_channels=cfg.DATASET.IN_CHANNELS, aspp_out=cfg.MODEL.ASPP.OUT_CHANNELS,
+                  atrous_channels=tuple(cfg.MODEL.ASPP.ATROUS_CHANNELS), low_level_out=cfg.MODEL.DECODER.LOW_LEVEL_OUT_CHANNELS,
+                  refine_channels=tuple(cfg.MODEL.DECODER.REFINE_CHANNELS))
+        if state_dict is not None:
+            self.state = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        elif cfg.MODEL.WEIGHT:
+            self.state = load_checkpoint(cfg.MODEL.WEIGHT)                      # :31-32
+        else:
+            self.state = random_state_dict(seed=getattr(cfg.MODEL, "SEED", 0), **kw)
+        check_state_dict(self.state, **kw)
+        self._nets = {}
+
+    def net_for(self, h, w):
+        """The compiled plan for an h x w input (built on first use, kept per size)."""
+        key = (int(h), int(w))
+        if key not in self._nets:
+            self._nets[key] = SegNet(self.state, key[0], key[1], precision=self.precision, device=self.device,
+                                     num_classes=self.num_classes)
+        return self._nets[key]
+
+    def segmentation_device(self, image_in):
+        """uint8 RGB [h,w,3] (ndarray or CUDA tensor) -> uint8 CUDA tensor [h/4-4, w/4-4]."""
+        h, w = int(image_in.shape[0]), int(image_in.shape[1])
+        net = self.net_for(h, w)
+        return net.forward(image_in)
+
+    def segmentation(self, image_in):
+        """semantic_segmentation.py:41-57: numpy (h, w, 3) RGB -> int64 numpy label map."""
+        labels = self.segmentation_device(image_in)
+        return labels.cpu().numpy().astype(np.int64)
+
+    def logits(self, image_in):
+        """float32 CUDA tensor [K, h', w'] (the reference's layout) of model(x, upsample_pred=False)."""
+        h, w = int(image_in.shape[0]), int(image_in.shape[1])
+        net = self.net_for(h, w)
+        net.forward(image_in)
+        return net.logits.permute(2, 0, 1)
+
+    @staticmethod
+    def resize_area(image, out_h, out_w):
+        """cv2.resize(..., INTER_AREA) slot of the node (vision_semantic_segmentation_node.py:92-98);
+        next row of SURVEY 8f.  Exact for integer scale factors (box mean), which is what IMAGE_SCALE = 0.5 gives."""
+        h, w = image.shape[:2]
+        if h % out_h == 0 and w % out_w == 0:
+            fy, fx = h // out_h, w // out_w
+            v = image.reshape(out_h, fy, out_w, fx, -1).astype(np.float32).mean(axis=(1, 3))
+            return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+        raise NotImplementedError("INTER_AREA for non-integer scale factors is not built yet")
+
+
+def smoke_segmentation(device):
+    """One small forward on the GPU against the torch-CPU oracle (called by __graft_entry__.smoke)."""
+    from oracle import network_oracle as no
+    from .config import get_network_cfg_defaults
+    cfg = get_network_cfg_defaults()
+    cfg.MODEL.PRECISION = "f32"
+    seg = SemanticSegmentation(cfg, device=device)
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(96, 128, 3), dtype=np.uint8)
+    got = seg.logits(img).cpu()
+    ref = no.forward_logits(seg.state, img)[0]
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert got.shape == ref.shape and err < 1e-3, "segmentation logits differ from the oracle: rel err %g" % err
+    agree = float((got.argmax(0) == ref.argmax(0)).float().mean())
+    print("smoke: segmentation f32 logits max rel err %.2e, argmax agreement %.4f" % (err, agree))
