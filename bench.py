@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fused frames/s on synthetic 1920x1080 frames + 120k-point clouds.
+
+One step = one pass of the hot path over one frame, inputs already resident in HBM:
+    segmentation forward (DeepLabV3+/ResNeXt-50 OS8, bf16 MFMA)  ->  uint8 label map (stays in HBM)
+    -> LiDAR projection + label gather + BEV vote + grid update (avl_fused_frame)
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), one camera stream and one
+private grid per rank, no data-path collective per frame; the shared global grid is formed by ONE
+all-reduce (sum) of the private grids, inside the timed region ("weak" scaling: per-GPU work fixed).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel = the
+1x1-conv MFMA GEMM, HIP-event time per launch) and `cpu_baseline` (the NumPy/torch-CPU oracle timed
+on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, NPTS = 1080, 1920, 120000
+GRID_RES, GRID_HALF = 0.2, 200.0          # 2000 x 2000 cells (BASELINE config C / D)
+PEAK_BF16_TFLOPS = 2500.0                 # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from vision_semantic_segmentation_amd import SemanticMapping, get_cfg_defaults, synthetic as syn
+    from vision_semantic_segmentation_amd.camera import camera_setup_1
+    from vision_semantic_segmentation_amd.mapping import PCD_ORIGIN_OFFSET
+    from vision_semantic_segmentation_amd.network import SegNet, random_state_dict
+    from vision_semantic_segmentation_amd.utils.logger import MyLogger
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- workload, resident in HBM (each rank its own camera stream: different seed)
+    rng = np.random.default_rng(1 + rank)
+    cam = camera_setup_1().scaled(1.0, H / 1440.0, imSize=[W, H])
+    image = torch.from_numpy(rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)).to(dev)
+    cloud = syn.make_cloud(rng, NPTS, cam.K, cam.R, cam.t, W, H)
+    points = torch.from_numpy(np.ascontiguousarray(cloud.T.astype(np.float32))).to(dev)       # [N,4] f32 (PointCloud2 layout)
+    cfg = get_cfg_defaults()
+    cfg.MAPPING.BOUNDARY = syn.centred_boundary(PCD_ORIGIN_OFFSET[:2], GRID_HALF)
+    cfg.MAPPING.RESOLUTION = GRID_RES
+    sm = SemanticMapping(cfg, device=dev, logger=MyLogger("bench", quiet=True))
+    sm.confusion_matrix = syn.log_confusion(5)
+    state = random_state_dict(0)
+    net = SegNet(state, H, W, precision=args.precision, device=dev)
+
+    def step():
+        labels = net.forward(image)
+        sm.frame_device(points, "velodyne", labels, None, cam, src_kind="classmap", image_size=(H, W))
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        sm.global_map()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        shared = sm.global_map()          # the one exchange step: private grids -> shared grid (RCCL all-reduce)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        fps = world * args.steps / elapsed
+        # ---- roofline of the dominant kernel (GEMM) from per-launch HIP events on the launch stream
+        prof = net.profile()
+        for _ in range(2):
+            for a, b in zip(prof, net.profile()):
+                a["ms"] = min(a["ms"], b["ms"])
+        gemm = [p for p in prof if p["kind"] == "gemm"]
+        g_ms, g_fl = sum(p["ms"] for p in gemm), sum(p["flops"] for p in gemm)
+        seg_ms, seg_fl = sum(p["ms"] for p in prof), sum(p["flops"] for p in prof)
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        achieved = g_fl / g_ms / 1e9
+        roofline = {"bound": "mfma", "kernel": "k_gemm (1x1 conv, %d launches/frame)" % len(gemm), "achieved": round(achieved, 1),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                    "flops_per_frame": g_fl, "ms_per_frame": round(g_ms, 4),
+                    "whole_net": {"gflop_per_frame": round(seg_fl / 1e9, 1), "ms_sum_of_ops": round(seg_ms, 3),
+                                  "tflops": round(seg_fl / seg_ms / 1e9, 1)}}
+        # ---- parity of this very workload: grid after one frame vs the oracle fed the GPU's label map
+        from oracle import mapping_oracle as mo
+        sm2 = SemanticMapping(cfg, device=dev, logger=MyLogger("bench", quiet=True))
+        sm2.confusion_matrix = sm.confusion_matrix
+        labels = net.forward(image)
+        sm2.frame_device(points, "velodyne", labels, None, cam, src_kind="classmap", image_size=(H, W))
+        sem = mo.semantic_image_from_labels(labels.cpu().numpy(), H, W)
+        grid = np.zeros((sm2.map_height, sm2.map_width, 5))
+        ocfg = dict(range_max=100.0, boundary=cfg.MAPPING.BOUNDARY, resolution=GRID_RES, label_names=mo.LABELS_NAMES,
+                    label_colors=mo.LABEL_COLORS, confusion_matrix=sm.confusion_matrix, use_pcd_intensity=True)
+        pcd64 = points.cpu().numpy().T.astype(np.float64)
+        t_map0 = time.perf_counter()
+        mo.mapping_frame(grid, pcd64, "velodyne", sem, None, cam.P, ocfg)
+        t_map = time.perf_counter() - t_map0
+        max_dlogodds = float(np.max(np.abs(sm2.map - grid)))
+
+        cpu_baseline = None
+        if not args.no_cpu_baseline:
+            cpu_baseline = cpu_baseline_leg(state, image.cpu().numpy(), pcd64, sem, cam, ocfg, t_map)
+
+        result = {
+            "metric": "fused frames/sec/GPU (1920x1080 + 120k pts) + max|dlog-odds| vs ref",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "per_gpu": round(fps / world, 2), "max_abs_dlogodds_vs_oracle": max_dlogodds,
+            "config": {"workload": "configs[2] full fuse: seg 1920x1080 + projection + 0.2 m BEV log-odds update, 120k pts, "
+                                   "2000x2000x5 f64 grid; weights random-init ResNeXt50-OS8 DeepLabV3+",
+                       "frame": [H, W], "points": NPTS, "grid": [sm.map_height, sm.map_width, sm.map_depth],
+                       "parallelism": "frame-parallel x%d, 1 grid all-reduce" % world},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+def cpu_baseline_leg(state, image, pcd64, sem, cam, ocfg, t_map_first):
+    """The oracle (a port of the reference's NumPy / PyTorch-CPU path) on this box's host cores.
+    Bounded sample: the mapping half at full size (min of 5), the network half on a 270x480 crop
+    (1/16 of the frame's pixels) scaled by the pixel ratio."""
+    import torch
+    from oracle import mapping_oracle as mo
+    from oracle import network_oracle as no
+    cores = torch.get_num_threads()
+    t_map = t_map_first
+    for _ in range(4):
+        grid = np.zeros((2000, 2000, 5))
+        t0 = time.perf_counter()
+        mo.mapping_frame(grid, pcd64, "velodyne", sem, None, cam.P, ocfg)
+        t_map = min(t_map, time.perf_counter() - t0)
+    crop = np.ascontiguousarray(image[:270, :480])
+    no.forward_logits(state, crop[:96, :128])          # warm-up
+    t0 = time.perf_counter()
+    no.forward_logits(state, crop)
+    t_net = (time.perf_counter() - t0) * (H * W) / (270.0 * 480.0)
+    return {"value": round(1.0 / (t_net + t_map), 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle mapping (NumPy, 1 thread) at full size: %.1f ms; oracle network (torch CPU fp32, %d threads) on a "
+                      "270x480 crop scaled x16 to 1080x1920: %.2f s" % (1e3 * t_map, cores, t_net)}
+
+
+if __name__ == "__main__":
+    main()

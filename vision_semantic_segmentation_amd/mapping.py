@@ -449,14 +449,8 @@ class SemanticMapping(object):
         own grid; since a frame's contribution never depends on the grid's content, the shared grid
         is the element-wise sum.  all_reduce (or reduce to ``dst``) over RCCL on a copy, so the private
         grid keeps accumulating.  Returns the CUDA tensor (valid on every rank, or on dst only)."""
-        import torch.distributed as dist
-        total = self.grid.map.clone()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            if dst is None:
-                dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
-            else:
-                dist.reduce(total, dst=dst, op=dist.ReduceOp.SUM, group=group)
-        return total
+        from .distributed import reduce_grids
+        return reduce_grids(self.grid.map, group=group, dst=dst)
 
     def save_inputs(self, path=None):
         """The reference dumps input_list with hickle (mapping.py:324-326); hickle is optional here,
