@@ -381,6 +381,8 @@ int validate_conv_op(const avl_seg_op& op) {
             AVL_REQUIRE(op.ksize == 3 && (op.stride == 1 || op.stride == 2) && op.dil >= 1 && op.pad == op.dil, "gconv geometry");
             AVL_REQUIRE(op.out_h == (op.in_h + 2 * op.pad - 2 * op.dil - 1) / op.stride + 1 &&
                         op.out_w == (op.in_w + 2 * op.pad - 2 * op.dil - 1) / op.stride + 1, "gconv output size");
+            if (op.w_layout == 1) return validate_gconv_mfma(op);
+            AVL_REQUIRE(op.w_layout == 0, "gconv weight layout %d", op.w_layout);
             break;
         }
         case AVL_OP_DWCONV:
@@ -400,6 +402,7 @@ int validate_conv_op(const avl_seg_op& op) {
 }
 
 int launch_conv_op(const avl_seg_op& op, hipStream_t s) {
+    if (op.kind == AVL_OP_GCONV && op.w_layout == 1) return launch_gconv_mfma(op, s);
     if (op.kind == AVL_OP_GEMV) {
         hipLaunchKernelGGL(k_gemv, dim3((op.out_c + 3) / 4), dim3(kThreads), 0, s, static_cast<const float*>(op.in),
                            static_cast<const float*>(op.weight), op.bias, static_cast<float*>(op.out), op.out_c, op.in_c, op.relu);

@@ -1,0 +1,152 @@
+// Grouped 3x3 convolution (torchvision Bottleneck.conv2, groups = 32) on the matrix cores, bf16.
+//
+// The 32 groups have 4/8/16/32 channels each (layer1..4), far too narrow for an MFMA tile, so the
+// host packs the weights of every 32-CHANNEL WINDOW as one dense block-diagonal [32 out][9 taps x 32 in]
+// matrix (zeros between different groups).  MFMA time is then a few microseconds per layer even with
+// the zeros; what bounds the kernel is bytes, so the work is organised around memory:
+//   * a workgroup owns an 8 x 32 output-pixel tile x 64 channels (two windows); the input tile with
+//     its dilation halo is staged ONCE into LDS (zero-filled outside the image), so each of the 9
+//     taps is an LDS read instead of another trip to L2;
+//   * LDS rows are one pixel = 128 B; 16-byte chunks are XOR-swizzled with the pixel index;
+//   * each wave keeps its window's 18 weight fragments (2 n-tiles x 9 taps) in registers for the
+//     whole tile and walks 8 sub-tiles of 16 pixels: 9 ds_read_b128 + 18 v_mfma_f32_16x16x32_bf16 each;
+//   * product is computed transposed (channels on MFMA rows, permuted) so a lane owns 8 consecutive
+//     output channels of one pixel: bias + ReLU + one 16-byte store per lane.
+#include "seg_types.h"
+
+namespace avl {
+namespace {
+
+constexpr int TW = 32;          // output tile width  (2 sub-tiles of 16 pixels)
+constexpr int CC = 64;          // channels per workgroup (2 windows of 32)
+
+struct GconvArgs {
+    const bf16* in;
+    const bf16* w;       // [window][nj 2][tap 9][i 16][ci 32]
+    const float* bias;   // [C]
+    bf16* out;
+    int H, W, in_ld, OH, OW, out_ld, C;
+    int stride, dil;
+    int th;              // output tile height (8, or 4 for stride 2)
+    int tiles_x, tiles_y, cchunks;
+};
+
+__global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int cchunk = bid % p.cchunks;
+    bid /= p.cchunks;
+    const int tx = bid % p.tiles_x, ty = bid / p.tiles_x;
+    const int oy0 = ty * p.th, ox0 = tx * TW;
+    const int s = p.stride, d = p.dil;
+    const int in_th = (p.th - 1) * s + 2 * d + 1, in_tw = (TW - 1) * s + 2 * d + 1;
+    const int iy0 = oy0 * s - d, ix0 = ox0 * s - d;
+    const int c0 = cchunk * CC;
+
+    // ---- stage the input tile (+halo) : pixel-major, 8 chunks of 16 B per pixel, zero outside the image
+    const int npix = in_th * in_tw;
+    for (int e = tid; e < npix * 8; e += 256) {
+        const int pix = e >> 3, chunk = e & 7;
+        const int ly = pix / in_tw, lx = pix - ly * in_tw;
+        const int iy = iy0 + ly, ix = ix0 + lx;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+            v = *reinterpret_cast<const uint4*>(p.in + ((long long)iy * p.W + ix) * p.in_ld + c0 + chunk * 8);
+        *reinterpret_cast<uint4*>(lds + pix * 128 + ((chunk ^ (pix & 7)) << 4)) = v;
+    }
+
+    // ---- this wave's window and its weight fragments (registers for the whole tile)
+    const int win = wave & 1;                  // window inside the 64-channel chunk
+    const int half = wave >> 1;                // which half of the tile's sub-tiles
+    const int fr = lane & 15, kq = lane >> 4;
+    bf16x8 wf[2][9];
+    {
+        const bf16* wp = p.w + (long long)(cchunk * 2 + win) * (2 * 9 * 16 * 32);
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                wf[nj][t] = *reinterpret_cast<const bf16x8*>(wp + ((nj * 9 + t) * 16 + fr) * 32 + kq * 8);
+    }
+    // lane's 8 output channels: window base + q*8 + nj*4 + r
+    const int cbase = c0 + win * 32 + kq * 8;
+    float bias[8];
+    {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cbase);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cbase + 4);
+        bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
+        bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+    }
+    __syncthreads();
+
+    const int nsub = p.th * (TW / 16);         // sub-tiles of 16 pixels in the tile
+    const int chunk_in = win * 4 + kq;         // this lane's 16-byte chunk of the pixel row (8 input channels)
+    for (int st = half; st < nsub; st += 2) {
+        const int sy = st >> 1, sx = (st & 1) * 16 + fr;        // output pixel (tile-local) of this lane
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int pix = (sy * s + ky * d) * in_tw + sx * s + kx * d;
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(lds + pix * 128 + ((chunk_in ^ (pix & 7)) << 4));
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ky * 3 + kx], a, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ky * 3 + kx], a, acc1, 0, 0, 0);
+            }
+        }
+        const int oy = oy0 + sy, ox = ox0 + sx;
+        if (oy < p.OH && ox < p.OW) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = fmaxf(acc0[r] + bias[r], 0.f);
+                v[4 + r] = fmaxf(acc1[r] + bias[4 + r], 0.f);
+            }
+            Vec8<bf16>::store(p.out + ((long long)oy * p.OW + ox) * p.out_ld + cbase, v);
+        }
+    }
+}
+
+}  // namespace
+
+int gconv_mfma_lds_bytes(int stride, int dil, int& th) {
+    th = stride == 1 ? 8 : 4;
+    const int in_th = (th - 1) * stride + 2 * dil + 1, in_tw = (TW - 1) * stride + 2 * dil + 1;
+    return in_th * in_tw * 128;
+}
+
+int launch_gconv_mfma(const avl_seg_op& op, hipStream_t s) {
+    GconvArgs a;
+    a.in = static_cast<const bf16*>(op.in);
+    a.w = static_cast<const bf16*>(op.weight);
+    a.bias = op.bias;
+    a.out = static_cast<bf16*>(op.out);
+    a.H = op.in_h; a.W = op.in_w; a.in_ld = op.in_ld; a.OH = op.out_h; a.OW = op.out_w; a.out_ld = op.out_ld; a.C = op.in_c;
+    a.stride = op.stride; a.dil = op.dil;
+    const int ldsb = gconv_mfma_lds_bytes(op.stride, op.dil, a.th);
+    a.tiles_x = (op.out_w + TW - 1) / TW;
+    a.tiles_y = (op.out_h + a.th - 1) / a.th;
+    a.cchunks = op.in_c / CC;
+    static int attr_bytes = 0;
+    if (ldsb > attr_bytes) {
+        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_bytes = 160 * 1024;
+    }
+    hipLaunchKernelGGL(k_gconv_mfma, dim3(a.tiles_x * a.tiles_y * a.cchunks), dim3(256), ldsb, s, a);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+int validate_gconv_mfma(const avl_seg_op& op) {
+    AVL_REQUIRE(op.dtype == AVL_BF16, "MFMA grouped conv is bf16 only");
+    AVL_REQUIRE(op.in_c % CC == 0, "MFMA grouped conv needs channels %% 64 == 0 (got %d)", op.in_c);
+    const int cg = op.in_c / op.groups;
+    AVL_REQUIRE(cg <= 32 && 32 % cg == 0, "MFMA grouped conv needs <= 32 channels per group dividing 32 (got %d)", cg);
+    int th;
+    AVL_REQUIRE(gconv_mfma_lds_bytes(op.stride, op.dil, th) <= 160 * 1024, "grouped conv tile does not fit LDS (dilation %d)", op.dil);
+    return AVL_OK;
+}
+
+}  // namespace avl

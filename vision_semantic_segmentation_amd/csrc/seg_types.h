@@ -56,5 +56,7 @@ int launch_gemm(const avl_seg_op& op, hipStream_t s);
 int validate_gemm(const avl_seg_op& op);
 int launch_conv_op(const avl_seg_op& op, hipStream_t s);
 int validate_conv_op(const avl_seg_op& op);
+int launch_gconv_mfma(const avl_seg_op& op, hipStream_t s);
+int validate_gconv_mfma(const avl_seg_op& op);
 
 }  // namespace avl

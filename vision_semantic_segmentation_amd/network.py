@@ -40,7 +40,7 @@ class AvlSegOp(C.Structure):
         ("out_h", C.c_int32), ("out_w", C.c_int32), ("out_c", C.c_int32), ("out_ld", C.c_int32), ("out_rows", C.c_int32),
         ("in2_ld", C.c_int32),
         ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32), ("groups", C.c_int32),
-        ("relu", C.c_int32), ("out_f32", C.c_int32), ("w_rows", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("relu", C.c_int32), ("out_f32", C.c_int32), ("w_rows", C.c_int32), ("w_layout", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -155,6 +155,29 @@ def fold_bn(state, conv_key, bn_prefix):
     s = state[bn_prefix + ".weight"].to(torch.float64) / torch.sqrt(state[bn_prefix + ".running_var"].to(torch.float64) + BN_EPS)
     b = state[bn_prefix + ".bias"].to(torch.float64) - state[bn_prefix + ".running_mean"].to(torch.float64) * s
     return w * s.view(-1, 1, 1, 1), b
+
+
+def pack_gconv_windows(w, groups):
+    """Grouped 3x3 weights [C][C/groups][3][3] (BN folded) -> dense block-diagonal 32-channel windows for the
+    MFMA kernel: [window][nj 2][tap 9][i 16][ci 32] where MFMA row i of n-tile nj is output channel
+    (i>>2)*8 + nj*4 + (i&3) of the window and ci is the input channel inside the window (zero when the two
+    channels belong to different groups)."""
+    C_ = w.shape[0]
+    cg = C_ // groups
+    nwin = C_ // 32
+    dense = torch.zeros((nwin, 32, 9, 32), dtype=torch.float64)              # [window][co_local][tap][ci_local]
+    wt = w.reshape(C_, cg, 9)
+    co = torch.arange(C_)
+    win, col = co // 32, co % 32
+    gbase = (col // cg) * cg                                                   # first window-local channel of co's group
+    for ci in range(cg):
+        dense[win, col, :, gbase + ci] = wt[co, ci, :]
+    i = torch.arange(16)
+    out = torch.empty((nwin, 2, 9, 16, 32), dtype=torch.float64)
+    for nj in range(2):
+        rows = (i >> 2) * 8 + nj * 4 + (i & 3)
+        out[:, nj] = dense[:, rows].permute(0, 2, 1, 3)                        # [win][tap][i][ci]
+    return out.reshape(-1)
 
 
 def _round_up(x, m):
@@ -305,11 +328,15 @@ class SegNet(object):
                 # conv2 3x3 grouped + bn2 + relu
                 w, b = fold_bn(st, p + ".conv2.weight", p + ".bn2")
                 cg = width // GROUPS
-                wg = w.reshape(GROUPS, cg, cg, 3, 3).permute(0, 3, 4, 2, 1).reshape(-1)   # [g][ky][kx][ci][co]
-                wg_d, bg_d = self._dev(wg, torch.float32), self._dev(b, torch.float32)
+                if self.precision == "bf16" and width % 64 == 0 and 32 % cg == 0:
+                    wg_d, layout = self._dev(pack_gconv_windows(w, GROUPS), torch.bfloat16), 1
+                else:
+                    wg = w.reshape(GROUPS, cg, cg, 3, 3).permute(0, 3, 4, 2, 1).reshape(-1)   # [g][ky][kx][ci][co]
+                    wg_d, layout = self._dev(wg, torch.float32), 0
+                bg_d = self._dev(b, torch.float32)
                 t2 = self._act(ohw[0] * ohw[1], width)
                 self._spatial(p + ".conv2", OP_GCONV, t1, hw, width, t2, ohw, width, wg_d, bg_d, ksize=3, stride=s, pad=d, dil=d,
-                              groups=GROUPS, relu=1)
+                              groups=GROUPS, relu=1, w_layout=layout)
                 self._release(t1)
                 # identity / downsample
                 if (p + ".downsample.0.weight") in st:
