@@ -175,7 +175,8 @@ typedef struct avl_seg_op {
     int32_t out_f32;         /* GEMM: write fp32 (the logits) instead of `dtype`                */
     int32_t w_rows;          /* GEMM: rows of `weight` allocated (out_c padded to the N tile)   */
     int32_t w_layout;        /* GCONV: 0 = float [group][tap][ci][co] (direct kernel),
-                                       1 = bf16 block-diagonal 32-channel windows [window][2][9][16][32] (MFMA kernel) */
+                                       1 = bf16 block-diagonal 32-channel windows [window][2][9][16][32] (MFMA kernel)
+                                STEM:  0 = float [7][7][3][64] (direct kernel), 1 = bf16 [4][6][16][32] (MFMA kernel)   */
     int32_t reserved[2];
 } avl_seg_op;
 

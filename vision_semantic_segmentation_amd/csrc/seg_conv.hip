@@ -139,15 +139,22 @@ __global__ void __launch_bounds__(kThreads) k_gconv(const T* __restrict__ in, in
 // ------------------------------------------------------------------------------ depthwise 3x3 conv
 // core/nn/modules/conv.py:131-134 (groups = in_channels) + folded BN + ReLU.
 // weight: float [9][C]; one lane = one output pixel x 8 channels.
+// Thread order is channel-SLAB major (64 channels = one 128-byte line per pixel, all pixels, then the next
+// slab): the workgroups in flight at any time then share a slab whose whole image (pixels x 128 B) fits the
+// XCD L2s, so the dilated taps (12/24/36 rows apart in ASPP) are L2 hits instead of HBM re-reads.
 template <typename T>
 __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, int H, int W, int C, int in_ld,
                                                     const float* __restrict__ w, const float* __restrict__ bias,
                                                     T* __restrict__ out, int OH, int OW, int out_ld, int pad, int dil, int relu) {
+    constexpr int SLAB8 = (sizeof(T) == 2) ? 8 : 4;       // 16-byte chunks per 128-byte line
     const int c8n = C / 8;
     const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+    const long long per_slab = (long long)OH * OW * SLAB8;
     if (idx >= (long long)OH * OW * c8n) return;
-    const int c8 = (int)(idx % c8n);
-    const int pix = (int)(idx / c8n), oy = pix / OW, ox = pix % OW;
+    const int slab = (int)(idx / per_slab);
+    const long long rem = idx - (long long)slab * per_slab;
+    const int c8 = slab * SLAB8 + (int)(rem % SLAB8);
+    const int pix = (int)(rem / SLAB8), oy = pix / OW, ox = pix % OW;
     float acc[8];
     {
         const float4 b0 = *reinterpret_cast<const float4*>(bias + c8 * 8);
@@ -222,14 +229,23 @@ __global__ void __launch_bounds__(kThreads) k_gap_partial(const T* __restrict__ 
         Vec8<float>::store(partial + (long long)blockIdx.x * C + c8 * 8, s);
     }
 }
-// stage 2: fixed-order sum of the partials, divide by M
+// stage 2: fixed-order sum of the partials, divide by M.  One workgroup = 32 channels x 8 slices of G.
 __global__ void __launch_bounds__(kThreads) k_gap_final(const float* __restrict__ partial, int G, int C, int M,
                                                        float* __restrict__ out) {
-    const int c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += partial[(long long)g * C + c];
-    out[c] = s / (float)M;
+    if (c < C)
+        for (int g = sl; g < G; g += 8) s += partial[(long long)g * C + c];
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cl];
+        out[c] = t / (float)M;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ gemv
@@ -325,7 +341,7 @@ int launch_typed(const avl_seg_op& op, hipStream_t s) {
             float* partial = static_cast<float*>(const_cast<void*>(op.in2));
             hipLaunchKernelGGL(k_gap_partial<T>, dim3(G), dim3(kThreads), 0, s, in, op.in_h * op.in_w, op.in_c, op.in_ld, partial);
             AVL_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_gap_final, dim3(blocks_for(op.in_c)), dim3(kThreads), 0, s, partial, G, op.in_c,
+            hipLaunchKernelGGL(k_gap_final, dim3((op.in_c + 31) / 32), dim3(kThreads), 0, s, partial, G, op.in_c,
                                op.in_h * op.in_w, static_cast<float*>(op.out));
             break;
         }
@@ -352,6 +368,7 @@ int validate_conv_op(const avl_seg_op& op) {
             AVL_REQUIRE(op.weight && op.bias && op.out_c == 64 && op.in_c == 3, "stem expects 3 -> 64 channels");
             AVL_REQUIRE(op.out_h == (op.in_h + 6 - 7) / 2 + 1 && op.out_w == (op.in_w + 6 - 7) / 2 + 1, "stem output size");
             AVL_REQUIRE(op.out_rows >= out_pix && op.out_ld >= 64 && (op.out_ld * es) % 16 == 0, "stem output buffer");
+            AVL_REQUIRE(op.w_layout == 0 || (op.w_layout == 1 && op.dtype == AVL_BF16), "stem weight layout %d", op.w_layout);
             return AVL_OK;
         case AVL_OP_GEMV:
             AVL_REQUIRE(op.weight && op.in_c > 0 && op.out_c > 0, "gemv shapes");
@@ -388,6 +405,7 @@ int validate_conv_op(const avl_seg_op& op) {
         case AVL_OP_DWCONV:
             AVL_REQUIRE(op.weight && op.bias && op.out_c == op.in_c && op.ksize == 3 && op.stride == 1 && op.dil >= 1 && op.pad >= 0, "dwconv geometry");
             AVL_REQUIRE(op.out_h == op.in_h + 2 * op.pad - 2 * op.dil && op.out_w == op.in_w + 2 * op.pad - 2 * op.dil, "dwconv output size");
+            AVL_REQUIRE(op.in_c % (es == 2 ? 64 : 32) == 0, "dwconv channels %d not a multiple of one 128-byte line", op.in_c);
             break;
         case AVL_OP_BILINEAR:
             AVL_REQUIRE(op.out_c == op.in_c, "bilinear channels");
@@ -403,6 +421,7 @@ int validate_conv_op(const avl_seg_op& op) {
 
 int launch_conv_op(const avl_seg_op& op, hipStream_t s) {
     if (op.kind == AVL_OP_GCONV && op.w_layout == 1) return launch_gconv_mfma(op, s);
+    if (op.kind == AVL_OP_STEM && op.w_layout == 1) return launch_stem_mfma(op, s);
     if (op.kind == AVL_OP_GEMV) {
         hipLaunchKernelGGL(k_gemv, dim3((op.out_c + 3) / 4), dim3(kThreads), 0, s, static_cast<const float*>(op.in),
                            static_cast<const float*>(op.weight), op.bias, static_cast<float*>(op.out), op.out_c, op.in_c, op.relu);

@@ -1,0 +1,114 @@
+// Stem on the matrix cores (bf16): uint8 RGB -> ToTensor/Normalize (semantic_segmentation.py:35-39) ->
+// 7x7 stride-2 pad-3 conv 3->64 (torchvision ResNet.conv1) + folded bn1 + ReLU, NHWC bf16 out.
+//
+// Implicit GEMM with K laid out as [ky 7][kx*3+ci padded 21 -> 24]: inside one kernel row the 21 taps are 21
+// CONTIGUOUS bytes of the image row, so a lane's 8-wide K fragment is 8 consecutive values of the normalised
+// tile in LDS (the 3 pad positions per row carry zero weights).  K = 7*24 = 168 -> 6 MFMA steps of 32 (the last
+// 24 are zero weights).  A workgroup converts an input tile (8x32 outputs -> 21x69 pixels) to normalised bf16 in
+// LDS once (zeros outside the image: padding applies to the NORMALISED image), keeps all 24 weight fragments in
+// registers and each wave walks 4 sub-tiles of 16 pixels: 21 LDS reads + 24 v_mfma_f32_16x16x32_bf16 per sub-tile.
+#include "seg_types.h"
+
+namespace avl {
+namespace {
+
+constexpr int S_TH = 8, S_TW = 32;
+constexpr int IN_TH = 2 * S_TH + 5, IN_TW = 2 * S_TW + 5;     // 21 x 69 input pixels
+constexpr int ROW = 224;                                      // bf16 values per LDS row (>= 69*3 + slack for the pad taps)
+
+struct StemArgs {
+    const unsigned char* img;
+    const bf16* w;        // [nj 4][step 6][i 16][k 32]
+    const float* bias;    // [64]
+    bf16* out;
+    int H, W, OH, OW, out_ld, tiles_x;
+};
+
+__global__ void __launch_bounds__(256) k_stem_mfma(StemArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16 tile[(IN_TH + 1) * ROW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+    const int oy0 = ty * S_TH, ox0 = tx * S_TW;
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int e = tid; e < (IN_TH + 1) * ROW; e += 256) {
+        const int ly = e / ROW, lc = e - ly * ROW;
+        const int lx = lc / 3, ci = lc - lx * 3;
+        const int iy = iy0 + ly, ix = ix0 + lx;
+        float v = 0.f;
+        if (ly < IN_TH && lx < IN_TW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+            v = ((float)p.img[((long long)iy * p.W + ix) * 3 + ci] / 255.0f - mean[ci]) / stdv[ci];
+        tile[e] = (bf16)v;
+    }
+    const int fr = lane & 15, kq = lane >> 4;
+    bf16x8 wf[4][6];
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int st = 0; st < 6; ++st)
+            wf[nj][st] = *reinterpret_cast<const bf16x8*>(p.w + ((nj * 6 + st) * 16 + fr) * 32 + kq * 8);
+    float bias[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + kq * 16 + 4 * j);
+        bias[4 * j] = b.x; bias[4 * j + 1] = b.y; bias[4 * j + 2] = b.z; bias[4 * j + 3] = b.w;
+    }
+    __syncthreads();
+
+    for (int sub = wave; sub < S_TH * (S_TW / 16); sub += 4) {
+        const int sy = sub >> 1, sx = (sub & 1) * 16 + fr;
+        f32x4 acc[4];
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) acc[nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 6; ++st) {
+            // chunk index q = st*4 + kq in [0,24): kernel row ky = q/3, 8-wide piece (q%3) of its 24 taps
+            const int q = st * 4 + kq;
+            const int ky = q / 3, piece = q - ky * 3;
+            bf16x8 a;
+            if (q < 21) {
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(tile + (sy * 2 + ky) * ROW + sx * 6 + piece * 8);
+                uint32_t u[4] = {src[0], src[1], src[2], src[3]};
+                __builtin_memcpy(&a, u, 16);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = (bf16)0.f;
+            }
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) acc[nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nj][st], a, acc[nj], 0, 0, 0);
+        }
+        const int oy = oy0 + sy, ox = ox0 + sx;
+        if (oy < p.OH && ox < p.OW) {
+            float lo[8], hi[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lo[r] = fmaxf(acc[0][r] + bias[r], 0.f);
+                lo[4 + r] = fmaxf(acc[1][r] + bias[4 + r], 0.f);
+                hi[r] = fmaxf(acc[2][r] + bias[8 + r], 0.f);
+                hi[4 + r] = fmaxf(acc[3][r] + bias[12 + r], 0.f);
+            }
+            bf16* op = p.out + ((long long)oy * p.OW + ox) * p.out_ld + kq * 16;
+            Vec8<bf16>::store(op, lo);
+            Vec8<bf16>::store(op + 8, hi);
+        }
+    }
+}
+
+}  // namespace
+
+int launch_stem_mfma(const avl_seg_op& op, hipStream_t s) {
+    StemArgs a;
+    a.img = static_cast<const unsigned char*>(op.in);
+    a.w = static_cast<const bf16*>(op.weight);
+    a.bias = op.bias;
+    a.out = static_cast<bf16*>(op.out);
+    a.H = op.in_h; a.W = op.in_w; a.OH = op.out_h; a.OW = op.out_w; a.out_ld = op.out_ld;
+    a.tiles_x = (op.out_w + S_TW - 1) / S_TW;
+    const int tiles_y = (op.out_h + S_TH - 1) / S_TH;
+    hipLaunchKernelGGL(k_stem_mfma, dim3(a.tiles_x * tiles_y), dim3(256), 0, s, a);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+}  // namespace avl

@@ -58,5 +58,6 @@ int launch_conv_op(const avl_seg_op& op, hipStream_t s);
 int validate_conv_op(const avl_seg_op& op);
 int launch_gconv_mfma(const avl_seg_op& op, hipStream_t s);
 int validate_gconv_mfma(const avl_seg_op& op);
+int launch_stem_mfma(const avl_seg_op& op, hipStream_t s);
 
 }  // namespace avl

@@ -157,6 +157,23 @@ def fold_bn(state, conv_key, bn_prefix):
     return w * s.view(-1, 1, 1, 1), b
 
 
+def pack_stem_mfma(w):
+    """Stem weights [64][3][7][7] (BN folded) -> [nj 4][step 6][i 16][k 32] for the MFMA stem kernel: MFMA row i of
+    n-tile nj is output channel (i>>2)*16 + nj*4 + (i&3); K position (step, k) is chunk q = step*4 + k//8 of 8 taps:
+    kernel row ky = q//3, tap t = (q%3)*8 + k%8 of that row's 24 slots (kx = t//3, ci = t%3; slots 21..23 and q >= 21 are zero)."""
+    out = torch.zeros((4, 6, 16, 32), dtype=torch.float64)
+    for nj in range(4):
+        for i in range(16):
+            n = (i >> 2) * 16 + nj * 4 + (i & 3)
+            for st in range(6):
+                for k in range(32):
+                    q, j = st * 4 + k // 8, k % 8
+                    t = (q % 3) * 8 + j
+                    if q < 21 and t < 21:
+                        out[nj, st, i, k] = w[n, t % 3, q // 3, t // 3]
+    return out.reshape(-1)
+
+
 def pack_gconv_windows(w, groups):
     """Grouped 3x3 weights [C][C/groups][3][3] (BN folded) -> dense block-diagonal 32-channel windows for the
     MFMA kernel: [window][nj 2][tap 9][i 16][ci 32] where MFMA row i of n-tile nj is output channel
@@ -293,12 +310,15 @@ class SegNet(object):
         # ---- stem: conv1 7x7 s2 + bn1 + relu (resnet.py:25-27), maxpool (:28)
         h2, w2 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         w, b = fold_bn(st, "backbone.conv1.weight", "backbone.bn1")
-        w_stem = self._dev(w.permute(2, 3, 1, 0).reshape(-1), torch.float32)          # [ky][kx][ci][co]
+        if self.precision == "bf16":
+            w_stem, stem_layout = self._dev(pack_stem_mfma(w), torch.bfloat16), 1
+        else:
+            w_stem, stem_layout = self._dev(w.permute(2, 3, 1, 0).reshape(-1), torch.float32), 0   # [ky][kx][ci][co]
         b_stem = self._dev(b, torch.float32)
         stem = self._act(h2 * w2, 64)
         self._op("backbone.conv1", OP_STEM, in_=self.image.data_ptr(), out=stem.data_ptr(), weight=w_stem.data_ptr(),
                  bias=b_stem.data_ptr(), in_h=H, in_w=W, in_c=3, in_ld=3, in_rows=H * W, out_h=h2, out_w=w2, out_c=64,
-                 out_ld=64, out_rows=stem.shape[0], ksize=7, stride=2, pad=3, dil=1, groups=1, relu=1)
+                 out_ld=64, out_rows=stem.shape[0], ksize=7, stride=2, pad=3, dil=1, groups=1, relu=1, w_layout=stem_layout)
         h4, w4 = (h2 + 2 - 3) // 2 + 1, (w2 + 2 - 3) // 2 + 1
         x = self._act(h4 * w4, 64)
         self._spatial("backbone.maxpool", OP_MAXPOOL, stem, (h2, w2), 64, x, (h4, w4), 64, ksize=3, stride=2, pad=1, dil=1)
