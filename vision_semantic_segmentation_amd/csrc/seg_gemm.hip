@@ -40,6 +40,26 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// The same DMA issued from inline asm: hipcc then does not know LDS is being written behind its back, so it
+// neither drains the queue (vmcnt(0)) in front of every ds_read nor before the next DMA; completion is
+// counted by hand (s_waitcnt vmcnt(N) + s_barrier in the caller).  M0 carries the wave-uniform LDS base.
+__device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(lds_byte_addr)
+        : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+
 template <typename T, int WM, int WN>
 __global__ void __launch_bounds__(WM* WN * 64) k_gemm(GemmArgs p) {
     constexpr int NW = WM * WN, BM = WM * 64, BN = WN * 64;
@@ -205,6 +225,197 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm(GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2 (bf16): persistent workgroups, 256 x 128 tile (8 waves = 2 per SIMD), 3-stage LDS ring.
+//   * one workgroup per CU walks tiles t = vb, vb + grid, ...; the K-steps of all its tiles form one
+//     stream, so the DMA for the NEXT tile's first steps is already in flight during the epilogue;
+//   * the ring keeps two K-steps ahead in flight: counted `s_waitcnt vmcnt(LPS)` + raw s_barrier
+//     (a __syncthreads() would drain the LDS-DMA queue with vmcnt(0));
+//   * weight-tile swizzle key is built from the row bits the permuted fragment rows actually vary in
+//     (conflict-free ds_read_b128 for both operands).
+template <int WM, int WN, int MI, int STAGES>
+__global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtiles) {
+    constexpr int NW = WM * WN, BM = WM * MI * 16, BN = WN * 64;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
+    constexpr int A_INSTR = BM / 8 / NW, W_INSTR = BN / 8 / NW;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nwg = gridDim.x;
+    int vb;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int total = mtiles * p.ntiles;
+    const int nk = p.K / 64;
+    const unsigned lds_base = lds_addr(lds);
+
+    // ---- producer side: per-lane DMA sources of the tile whose stages are being issued
+    const int srow = lane >> 3, schunk = lane & 7;
+    const char* a_src[A_INSTR];
+    const char* w_src[W_INSTR];
+    int pt = vb, pk = 0, issued = 0;
+    auto set_tile = [&](int t) {
+        const int nt = t % p.ntiles, mt = t / p.ntiles;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int r = (i * NW + wave) * 8 + srow;
+            a_src[i] = static_cast<const char*>(p.A) + (long long)(mt * BM + r) * p.lda * 2 + ((schunk ^ (r & 7)) << 4);
+        }
+#pragma unroll
+        for (int i = 0; i < W_INSTR; ++i) {
+            const int r = (i * NW + wave) * 8 + srow;
+            const int key = ((r >> 1) & 1) | (((r >> 4) & 3) << 1);
+            w_src[i] = static_cast<const char*>(p.W) + (long long)(nt * BN + r) * p.K * 2 + ((schunk ^ key) << 4);
+        }
+    };
+    auto issue = [&]() {
+        const unsigned base = lds_base + (issued % STAGES) * BUF + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) glds16_asm(a_src[i] + (long long)pk * 128, base + i * NW * 1024);
+#pragma unroll
+        for (int i = 0; i < W_INSTR; ++i) glds16_asm(w_src[i] + (long long)pk * 128, base + A_BYTES + i * NW * 1024);
+        ++issued;
+        if (++pk == nk) {
+            pk = 0;
+            pt += nwg;
+            if (pt < total) set_tile(pt);
+        }
+    };
+    if (pt < total) set_tile(pt);
+#pragma unroll
+    for (int i = 0; i < STAGES - 1; ++i)
+        if (pt < total) issue();
+
+    // ---- consumer side
+    const int fr = lane & 15, kq = lane >> 4;
+    int a_off[MI], w_off[4], a_key[MI], w_key[4];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * (MI * 16) + mi * 16 + fr;
+        a_off[mi] = row * 128;
+        a_key[mi] = row & 7;
+    }
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) {
+        const int row = wn * 64 + (fr >> 2) * 16 + nj * 4 + (fr & 3);
+        w_off[nj] = A_BYTES + row * 128;
+        w_key[nj] = ((row >> 1) & 1) | (((row >> 4) & 3) << 1);
+    }
+    // The accumulators start from the bias, so the epilogue issues no load whose result could still be
+    // pending when the K loop resumes (hipcc would then put a vmcnt(0) in front of every K-step's ds_reads).
+    f32x4 acc[MI][4];
+    auto init_acc = [&](int t) {
+        const int nb = (t % p.ntiles) * BN + wn * 64 + kq * 16;
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + nb + 4 * nj);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][nj] = f32x4{b.x, b.y, b.z, b.w};
+        }
+    };
+    if (vb < total) init_acc(vb);
+
+    int g = 0;   // K-steps consumed so far
+    for (int t = vb; t < total; t += nwg) {
+        const int nt = t % p.ntiles, mt = t / p.ntiles;
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            // stage g has landed (this wave's share); stage g+1 may stay in flight
+            if (STAGES >= 3 && issued > g + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + W_INSTR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (pt < total) issue();                       // stage g+2 -> the slot consumed in step g-1
+            const char* base = lds + (g % STAGES) * BUF;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int chunk = kk * 4 + kq;
+                bf16x8 af[MI], wf[4];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(base + a_off[mi] + ((chunk ^ a_key[mi]) << 4));
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) wf[nj] = *reinterpret_cast<const bf16x8*>(base + w_off[nj] + ((chunk ^ w_key[nj]) << 4));
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < 4; ++nj)
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nj], af[mi], acc[mi][nj], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        // ---- epilogue of tile t (the next tile's first stages are already in flight).  All residual loads
+        // are issued before the first one is consumed, so their latency is paid once per tile, not per sub-tile.
+        const int nbase = nt * BN + wn * 64 + kq * 16;
+        const bool ncol_ok = nbase + 16 <= p.N;
+        constexpr int EB = 4;                       // sub-tiles per epilogue batch (residual registers: 8 per sub-tile)
+#pragma unroll
+        for (int b0 = 0; b0 < MI; b0 += EB) {
+            bf16x8 res[EB][2];
+            if (p.R) {
+#pragma unroll
+                for (int e = 0; e < EB; ++e) {
+                    const int m = mt * BM + wm * (MI * 16) + (b0 + e) * 16 + fr;
+                    if (m < p.M && ncol_ok) {
+                        const bf16* rp = static_cast<const bf16*>(p.R) + (long long)m * p.ldr + nbase;
+                        res[e][0] = *reinterpret_cast<const bf16x8*>(rp);
+                        res[e][1] = *reinterpret_cast<const bf16x8*>(rp + 8);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                const int mi = b0 + e;
+                const int m = mt * BM + wm * (MI * 16) + mi * 16 + fr;
+                if (m < p.M && ncol_ok) {
+                    float v[16];
+#pragma unroll
+                    for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[nj * 4 + r] = acc[mi][nj][r];
+                    if (p.R) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { v[i] += (float)res[e][0][i]; v[8 + i] += (float)res[e][1][i]; }
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+                    }
+                    bf16* cp = static_cast<bf16*>(p.C) + (long long)m * p.ldc + nbase;
+                    float lo[8], hi[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { lo[i] = v[i]; hi[i] = v[8 + i]; }
+                    Vec8<bf16>::store(cp, lo);
+                    Vec8<bf16>::store(cp + 8, hi);
+                }
+            }
+        }
+        if (t + nwg < total) init_acc(t + nwg);
+    }
+}
+
+template <int WM, int WN, int MI, int STAGES>
+int launch_ring(const GemmArgs& a0, int M, hipStream_t s) {
+    constexpr int BM = WM * MI * 16, BN = WN * 64, LDS = STAGES * (BM + BN) * 128;
+    static_assert(LDS <= 160 * 1024, "ring does not fit LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<WM, WN, MI, STAGES>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    GemmArgs a = a0;
+    a.ntiles = (a.N + BN - 1) / BN;
+    const int mtiles = (M + BM - 1) / BM;
+    const int total = mtiles * a.ntiles;
+    const int grid = total < 256 ? total : 256;
+    hipLaunchKernelGGL((k_gemm_ring<WM, WN, MI, STAGES>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
 template <typename T, int WM, int WN>
 int launch_cfg(const GemmArgs& a, int mtiles, hipStream_t s) {
     constexpr int LDS = 2 * (WM * 64 + WN * 64) * 128;
@@ -259,6 +470,18 @@ int launch_gemm(const avl_seg_op& op, hipStream_t s) {
     const TileCfg t = pick_tile(op);
     const int mtiles = (a.M + t.bm - 1) / t.bm;
     a.ntiles = (a.N + t.bn - 1) / t.bn;
+    // bf16 variants.  w_layout: 0 = pick by shape, 1 = v1 (128x128, 2 LDS buffers, 2 workgroups/CU),
+    // 2 = ring 256x128 x3 stages, 3 = ring 256x256 x2 stages, 4 = ring 256x128 (4 waves) x3 stages.
+    // 256x256 halves the L2->LDS bytes per flop (the measured limiter) but needs >= ~200 tiles to fill 256 CUs.
+    if (op.dtype == AVL_BF16 && op.w_layout != 1 && t.bn == 128 && !op.out_f32 && a.N % 128 == 0 &&
+        op.in_rows >= (a.M + 255) / 256 * 256) {
+        const bool can256 = a.N % 256 == 0 && op.w_rows % 256 == 0;
+        int v = op.w_layout;
+        if (v == 0) v = (can256 && ((a.M + 255) / 256) * (a.N / 256) >= 192) ? 3 : 2;
+        if (v == 3 && can256) return launch_ring<2, 4, 8, 2>(a, a.M, s);
+        if (v == 4) return launch_ring<2, 2, 8, 3>(a, a.M, s);
+        return launch_ring<4, 2, 4, 3>(a, a.M, s);
+    }
     if (op.dtype == AVL_BF16) {
         if (t.bn == 64) return launch_cfg<bf16, 4, 1>(a, mtiles, s);
         return launch_cfg<bf16, 2, 2>(a, mtiles, s);

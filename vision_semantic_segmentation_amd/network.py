@@ -270,7 +270,7 @@ class SegNet(object):
         """1x1 conv.  w float64 [cout][cin] (BN folded), b float64 [cout]."""
         h, wd = hw
         cout = w.shape[0]
-        w_rows = _round_up(cout, 128)
+        w_rows = _round_up(cout, 256)
         wp = torch.zeros((w_rows, cin), dtype=torch.float64)
         wp[:cout] = w.reshape(cout, cin)
         wdev = self._dev(wp, self.act_dtype)
@@ -422,7 +422,7 @@ class SegNet(object):
         gap_partial = torch.zeros((256, fc), dtype=torch.float32, device=dev)
         gap_vec = torch.zeros(fc, dtype=torch.float32, device=dev)
         pool_vec = torch.zeros(npool, dtype=torch.float32, device=dev)
-        proj_bias = torch.zeros(_round_up(aspp_out, 128), dtype=torch.float32, device=dev)
+        proj_bias = torch.zeros(_round_up(aspp_out, 256), dtype=torch.float32, device=dev)
         self._keep += [gap_partial, gap_vec, pool_vec, proj_bias]
         fp, fld, frows = self._view(feat)
         self._op("aspp.global_avg_pool.0", OP_GAP, in_=fp, in2=gap_partial.data_ptr(), out=gap_vec.data_ptr(), in_h=fhw[0], in_w=fhw[1],
