@@ -16,6 +16,7 @@ ap.add_argument("--w", type=int, default=1920)
 ap.add_argument("--precision", default="bf16")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--top", type=int, default=25)
+ap.add_argument("--kind", default="")
 a = ap.parse_args()
 
 net = SegNet(random_state_dict(0), a.h, a.w, precision=a.precision, device="cuda:0")
@@ -41,7 +42,8 @@ print("%-10s %5s %9s %9s %9s %9s" % ("kind", "n", "ms", "GFLOP", "TFLOP/s", "GB/
 for kname, (ms, f, b, n) in sorted(kinds.items(), key=lambda kv: -kv[1][0]):
     print("%-10s %5d %9.3f %9.1f %9.1f %9.1f" % (kname, n, ms, f / 1e9, f / ms / 1e9 if ms else 0, b / ms / 1e6 if ms else 0))
 print("--- top ops")
-for p in sorted(best, key=lambda p: -p["ms"])[:a.top]:
+sel = [p for p in best if (not a.kind or p["kind"] in a.kind.split(","))]
+for p in (sel if a.kind else sorted(sel, key=lambda p: -p["ms"])[:a.top]):
     print("%-46s %-8s %8.3f ms %8.1f GFLOP %7.1f TF/s %8.1f GB/s" % (p["name"], p["kind"], p["ms"], p["flops"] / 1e9,
                                                                    p["flops"] / p["ms"] / 1e9, p["bytes"] / p["ms"] / 1e6))
 # whole-plan timing without per-op events

@@ -45,16 +45,32 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs p) {
     const int iy0 = oy0 * s - d, ix0 = ox0 * s - d;
     const int c0 = cchunk * CC;
 
-    // ---- stage the input tile (+halo) : pixel-major, 8 chunks of 16 B per pixel, zero outside the image
+    // ---- stage the input tile (+halo) by LDS-DMA: one wave-instruction = 8 pixels x 128 B, all of a wave's
+    // transfers in flight at once.  The DMA writes LDS lane-linearly, so the chunk swizzle goes on the SOURCE
+    // address.  Pixels outside the image are fetched from a clamped address and zeroed afterwards.
     const int npix = in_th * in_tw;
-    for (int e = tid; e < npix * 8; e += 256) {
-        const int pix = e >> 3, chunk = e & 7;
-        const int ly = pix / in_tw, lx = pix - ly * in_tw;
-        const int iy = iy0 + ly, ix = ix0 + lx;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-            v = *reinterpret_cast<const uint4*>(p.in + ((long long)iy * p.W + ix) * p.in_ld + c0 + chunk * 8);
-        *reinterpret_cast<uint4*>(lds + pix * 128 + ((chunk ^ (pix & 7)) << 4)) = v;
+    const int ngroups = (npix + 7) >> 3;
+    unsigned oob = 0;
+    {
+        const int prow = lane >> 3, cphys = lane & 7;
+        int it = 0;
+        for (int gi = wave; gi < ngroups; gi += 4, ++it) {
+            const int pix = gi * 8 + prow;
+            const int ly = pix / in_tw, lx = pix - ly * in_tw;
+            const int iy = iy0 + ly, ix = ix0 + lx;
+            const bool inside = pix < npix && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+            const bf16* src = p.in + ((long long)cy * p.W + cx) * p.in_ld + c0 + ((cphys ^ (pix & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + gi * 1024), 16, 0, 0);
+            oob |= (inside ? 0u : 1u) << it;
+        }
+        if (oob) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            it = 0;
+            for (int gi = wave; gi < ngroups; gi += 4, ++it)
+                if ((oob >> it) & 1u) *reinterpret_cast<uint4*>(lds + gi * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
 
     // ---- this wave's window and its weight fragments (registers for the whole tile)
@@ -114,7 +130,7 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs p) {
 int gconv_mfma_lds_bytes(int stride, int dil, int& th) {
     th = stride == 1 ? 8 : 4;
     const int in_th = (th - 1) * stride + 2 * dil + 1, in_tw = (TW - 1) * stride + 2 * dil + 1;
-    return in_th * in_tw * 128;
+    return ((in_th * in_tw + 7) / 8) * 1024;      // whole 8-pixel DMA groups
 }
 
 int launch_gconv_mfma(const avl_seg_op& op, hipStream_t s) {
