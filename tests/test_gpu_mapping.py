@@ -206,3 +206,37 @@ def test_full_size_properties(cuda_device):
         sm.frame_device(pcd, "velodyne", img_d, None, cam)
         mo.mapping_frame(grid, pcd, "velodyne", image, None, cam.P, cfg)
         assert np.array_equal(sm.map, grid)
+
+
+def test_callbacks_and_replay(cuda_device, tmp_path):
+    """The ROS-shaped path: pcd/pose/image callbacks with nearest-stamp matching (mapping.py:172-290), input
+    recording, and the offline replay driver (mapping_replay.py:175-192) reproducing the same grid."""
+    from vision_semantic_segmentation_amd import replay
+    from vision_semantic_segmentation_amd.utils import Header, Message, Pose, Stamp
+    g = np.load([c for c in CASES if "W_world" in c][0])
+    boundary, res = g["boundary"].tolist(), float(g["resolution"])
+    sm = make_sm(boundary, res, g["cm"], g["use_intensity"], cuda_device)
+    sm.record_inputs = True
+    sm.cam6.P = g["P"]                      # the fixture's camera (cam6 intrinsics at this image size)
+    pose = Pose.from_array(g["pose7"])
+    pcd2 = g["pcd"].copy()
+    pcd2[0:2] += 0.37
+    # two clouds and poses around two image stamps; the nearest one must be picked
+    sm.pcd_callback(Message(Header(Stamp(10, 0), "map"), points=g["pcd"]))
+    sm.pcd_callback(Message(Header(Stamp(11, 0), "map"), points=pcd2.T))            # [N,4] accepted too
+    sm.pose_callback(Message(Header(Stamp(10, 0)), pose=pose))
+    sm.pose_callback(Message(Header(Stamp(11, 0)), pose=pose))
+    sm.image_callback(Message(Header(Stamp(10, 100), "camera6"), data=g["image"]))
+    assert np.array_equal(sm.map, dense(g["map_idx"], g["map_val"], sm.map.shape))
+    sm.image_callback(Message(Header(Stamp(10, 900000000), "camera6"), data=g["image"]))
+    assert np.array_equal(sm.map, dense(g["map2_idx"], g["map2_val"], sm.map.shape))
+    with pytest.raises(ValueError):
+        sm.image_callback(Message(Header(Stamp(12, 0), "camera9"), data=g["image"]))
+    # record -> save -> replay
+    d = str(tmp_path)
+    sm.save_inputs(d)
+    frames = replay.load_frames(d)
+    assert len(frames) == 2 and frames[0]["pcd_frame_id"] == "map"
+    sm2 = make_sm(boundary, res, g["cm"], g["use_intensity"], cuda_device)
+    grid = replay.mapping_replay(sm2, frames, _Cam(g["P"]))
+    assert np.array_equal(grid, sm.map)
