@@ -18,6 +18,8 @@
 //   * workgroup ids are remapped so that the tiles sharing an activation panel run on one XCD (L2).
 //   * T = bf16 : v_mfma_f32_16x16x32_bf16, fp32 accumulate.
 //     T = float: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) -- the reference-precision mode.
+#include <cstdlib>
+
 #include "seg_types.h"
 
 namespace avl {
@@ -233,7 +235,7 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm(GemmArgs p) {
 //     (a __syncthreads() would drain the LDS-DMA queue with vmcnt(0));
 //   * weight-tile swizzle key is built from the row bits the permuted fragment rows actually vary in
 //     (conflict-free ds_read_b128 for both operands).
-template <int WM, int WN, int MI, int STAGES>
+template <int WM, int WN, int MI, int STAGES, int PROBE = 0>
 __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtiles) {
     constexpr int NW = WM * WN, BM = WM * MI * 16, BN = WN * 64;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
@@ -272,19 +274,26 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtile
             w_src[i] = static_cast<const char*>(p.W) + (long long)(nt * BN + r) * p.K * 2 + ((schunk ^ key) << 4);
         }
     };
-    auto issue = [&]() {
+    // one stage = A_INSTR + W_INSTR DMA instructions per wave; issue_part(h, NP) sends the h-th of NP equal shares
+    // (so the instructions can be spread between MFMA groups instead of queueing up in front of them)
+    auto issue_part = [&](int h, int np) {
         const unsigned base = lds_base + (issued % STAGES) * BUF + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) glds16_asm(a_src[i] + (long long)pk * 128, base + i * NW * 1024);
+        for (int i = 0; i < A_INSTR; ++i)
+            if (i * np / A_INSTR == h) glds16_asm(a_src[i] + (long long)pk * 128, base + i * NW * 1024);
 #pragma unroll
-        for (int i = 0; i < W_INSTR; ++i) glds16_asm(w_src[i] + (long long)pk * 128, base + A_BYTES + i * NW * 1024);
-        ++issued;
-        if (++pk == nk) {
-            pk = 0;
-            pt += nwg;
-            if (pt < total) set_tile(pt);
+        for (int i = 0; i < W_INSTR; ++i)
+            if (i * np / W_INSTR == h) glds16_asm(w_src[i] + (long long)pk * 128, base + A_BYTES + i * NW * 1024);
+        if (h == np - 1) {
+            ++issued;
+            if (++pk == nk) {
+                pk = 0;
+                pt += nwg;
+                if (pt < total) set_tile(pt);
+            }
         }
     };
+    auto issue = [&]() { issue_part(0, 1); };
     if (pt < total) set_tile(pt);
 #pragma unroll
     for (int i = 0; i < STAGES - 1; ++i)
@@ -327,24 +336,51 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtile
             if (STAGES >= 3 && issued > g + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + W_INSTR) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (pt < total) issue();                       // stage g+2 -> the slot consumed in step g-1
+            const bool feed = pt < total;                  // stage g+STAGES-1 -> the slot consumed in step g-1
             const char* base = lds + (g % STAGES) * BUF;
+            if (PROBE == 1) { if (feed) issue(); continue; }      // DMA only
+            auto rd_w = [&](int kk, int nj) { return *reinterpret_cast<const bf16x8*>(base + w_off[nj] + (((kk * 4 + kq) ^ w_key[nj]) << 4)); };
+            auto rd_a = [&](int kk, int mi) { return *reinterpret_cast<const bf16x8*>(base + a_off[mi] + (((kk * 4 + kq) ^ a_key[mi]) << 4)); };
+            // The step is cut into 4 MFMA groups; the next stage's DMA instructions and the second K-half's fragment
+            // reads are placed BETWEEN the groups (a DMA burst issued in one go in front of the MFMAs was measured to
+            // serialise with them: DMA-only 75 us + MFMA-only 65 us = 131 us for layer4.conv1).
+            constexpr int H = MI / 2;
+            bf16x8 wa[4], wb[4], af[MI];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int chunk = kk * 4 + kq;
-                bf16x8 af[MI], wf[4];
+            for (int nj = 0; nj < 4; ++nj) wa[nj] = rd_w(0, nj);
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(base + a_off[mi] + ((chunk ^ a_key[mi]) << 4));
+            for (int mi = 0; mi < MI; ++mi) af[mi] = rd_a(0, mi);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj) wf[nj] = *reinterpret_cast<const bf16x8*>(base + w_off[nj] + ((chunk ^ w_key[nj]) << 4));
-                __builtin_amdgcn_s_setprio(1);
+            for (int mi = 0; mi < H; ++mi)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nj], af[mi], acc[mi][nj], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (feed) issue_part(0, 2);
 #pragma unroll
-                    for (int nj = 0; nj < 4; ++nj)
-                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nj], af[mi], acc[mi][nj], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-            }
+            for (int nj = 0; nj < 4; ++nj) wb[nj] = rd_w(1, nj);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = H; mi < MI; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nj], af[mi], acc[mi][nj], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < H; ++mi) af[mi] = rd_a(1, mi);
+            if (feed) issue_part(1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < H; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nj], af[mi], acc[mi][nj], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = H; mi < MI; ++mi) af[mi] = rd_a(1, mi);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = H; mi < MI; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nj], af[mi], acc[mi][nj], 0, 0, 0);
         }
         // ---- epilogue of tile t (the next tile's first stages are already in flight).  All residual loads
         // are issued before the first one is consumed, so their latency is paid once per tile, not per sub-tile.
@@ -411,7 +447,15 @@ int launch_ring(const GemmArgs& a0, int M, hipStream_t s) {
     const int mtiles = (M + BM - 1) / BM;
     const int total = mtiles * a.ntiles;
     const int grid = total < 256 ? total : 256;
-    hipLaunchKernelGGL((k_gemm_ring<WM, WN, MI, STAGES>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
+    static const int probe = getenv("AVL_GEMM_PROBE") ? atoi(getenv("AVL_GEMM_PROBE")) : 0;   // timing experiments only
+    if (probe == 1) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<WM, WN, MI, STAGES, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipLaunchKernelGGL((k_gemm_ring<WM, WN, MI, STAGES, 1>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
+    } else if (probe == 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<WM, WN, MI, STAGES, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipLaunchKernelGGL((k_gemm_ring<WM, WN, MI, STAGES, 2>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
+    } else
+        hipLaunchKernelGGL((k_gemm_ring<WM, WN, MI, STAGES>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
