@@ -32,7 +32,9 @@ def run(n, res, half, layout, iters=200):
         pts = torch.from_numpy(pcd).to(dev)
     for _ in range(10):
         sm.frame_device(pts, "velodyne", small, None, cam, src_kind="classmap", image_size=(H, W))
-    u = int(sm.grid.counter[0].item())
+    sm.map = np.zeros((sm.map_height, sm.map_width, sm.map_depth))
+    sm.frame_device(pts, "velodyne", small, None, cam, src_kind="classmap", image_size=(H, W))
+    u = int((sm.map_dev != 0).any(dim=2).sum().item())           # touched cells of one frame (works in list and sweep mode)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()

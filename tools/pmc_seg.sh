@@ -9,19 +9,31 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/p1 -- pyth
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/p2 -- python3 $ARGS > $OUT/p2.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $OUT/p3 -- python3 $ARGS > $OUT/p3.log 2>&1
 python3 - <<'PY'
-import csv, glob, collections
-agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter(); dur=collections.defaultdict(float)
+import csv, glob, collections, json, re
+def fam(name):
+    m = re.search(r"k_[a-z0-9_]+", name)
+    base = m.group(0) if m else name[:30]
+    t = re.search(r"k_gemm_ring<(\d+), (\d+), (\d+), (\d+)", name) or re.search(r"k_gemm_ringILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)", name)
+    if t: base += "<%s,%s,%s,%s>" % t.groups()
+    return base
+agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
 for f in glob.glob('gpurun_out/pmc_seg/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        k=r['Kernel_Name'].split('(')[0][-40:]
+        k=fam(r['Kernel_Name'])
         agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
-        if r['Counter_Name'] in ('FETCH_SIZE',): n[k]+=1
-print("%-42s %5s %10s %10s %8s %8s %8s %8s" % ("kernel","calls","fetchMB*2","writeMB","L2hit","waitany","waitinst","active"))
+        if r['Counter_Name']=='FETCH_SIZE': n[k]+=1
+out=[]
+print("%-30s %6s %12s %10s %7s %8s %8s %8s" % ("kernel","calls","fetchMB(x2)","writeMB","L2hit","waitany","waitinst","active"))
 for k,v in sorted(agg.items(), key=lambda kv:-kv[1].get('FETCH_SIZE',0)):
-    if n[k]==0: continue
     c=n[k]
+    if c==0: continue
     hit=v['TCC_HIT_sum']/max(1,(v['TCC_HIT_sum']+v['TCC_MISS_sum']))
     wc=max(1,v['SQ_WAVE_CYCLES'])
-    # FETCH_SIZE / WRITE_SIZE are in KB; gfx950 FETCH_SIZE reads 1/2 of wide streaming reads (MI355X_MICROARCH.md HBM) -> doubled
-    print("%-42s %5d %10.1f %10.1f %8.3f %8.3f %8.3f %8.3f" % (k, c, 2*v['FETCH_SIZE']/1024/c* (c/ c), v['WRITE_SIZE']/1024/c, hit, v['SQ_WAIT_ANY']/wc, v['SQ_WAIT_INST_ANY']/wc, v['SQ_ACTIVE_INST_ANY']/wc))
+    # FETCH_SIZE / WRITE_SIZE are in KB.  gfx950: FETCH_SIZE counts 1/2 of the bytes of wide (16 B/lane) coalesced reads
+    # (MI355X_MICROARCH.md, HBM): doubled here; WRITE_SIZE is exact for 16 B/lane stores.
+    row=dict(kernel=k, launches_profiled=c, fetch_MB_per_launch=2*v['FETCH_SIZE']/1024/c, write_MB_per_launch=v['WRITE_SIZE']/1024/c,
+             l2_hit=hit, wait_any=v['SQ_WAIT_ANY']/wc, wait_inst=v['SQ_WAIT_INST_ANY']/wc, active=v['SQ_ACTIVE_INST_ANY']/wc)
+    out.append(row)
+    print("%-30s %6d %12.1f %10.1f %7.3f %8.3f %8.3f %8.3f" % (k, c, row['fetch_MB_per_launch'], row['write_MB_per_launch'], hit, row['wait_any'], row['wait_inst'], row['active']))
+json.dump(out, open('gpurun_out/pmc_seg/summary.json','w'), indent=1)
 PY

@@ -14,6 +14,7 @@
 #include "avl_common.h"
 
 #include <climits>
+#include <cstdlib>
 
 namespace {
 
@@ -140,6 +141,12 @@ __device__ __forceinline__ void cast_vote(unsigned* cell_mask, int* touched, int
     if (first) touched[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = cell;
 }
 
+// Dense clouds: no touched list -- a fire-and-forget OR (no-return atomic, nothing depends on it); the apply
+// pass then sweeps the whole mask instead of a list (k_grid_apply_scan).
+__device__ __forceinline__ void cast_vote_nolist(unsigned* cell_mask, int cell, unsigned vote) {
+    if (cell >= 0 && vote != 0) atomicOr(&cell_mask[cell], vote);
+}
+
 // ---------------------------------------------------------------- projection only (:367-383)
 __global__ void __launch_bounds__(kBlock) k_project_points(PtsView pv, ProjParams pp, int* __restrict__ out_ixy,
                                                            unsigned char* __restrict__ out_mask) {
@@ -254,7 +261,7 @@ __global__ void __launch_bounds__(kBlock) k_vote_labelled(const double* __restri
 }
 
 // ---------------------------------------------------------------- fused project + vote
-template <int SRC>
+template <int SRC, bool LIST>
 __global__ void __launch_bounds__(kBlock) k_fused_vote(PtsView pv, ProjParams pp, GridParams g,
                                                        const unsigned char* __restrict__ src, int src_w, int src_h,
                                                        LutParams lut, unsigned* __restrict__ cell_mask,
@@ -283,7 +290,8 @@ __global__ void __launch_bounds__(kBlock) k_fused_vote(PtsView pv, ProjParams pp
             }
         }
     }
-    cast_vote(cell_mask, touched, counter, cell, vote);
+    if (LIST) cast_vote(cell_mask, touched, counter, cell, vote);
+    else cast_vote_nolist(cell_mask, cell, vote);
 }
 
 // ---------------------------------------------------------------- touched cells -> grid (:424,437)
@@ -318,6 +326,30 @@ __global__ void __launch_bounds__(kBlock) k_grid_apply(MapT* __restrict__ map, M
 #pragma unroll
         for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
             if (c < C) row[c] = (MapT)v[c];
+    }
+}
+
+// Sweep variant of the apply pass for dense clouds: every lane inspects 4 consecutive cells' masks (one
+// 16-byte load); non-zero ones are applied exactly like k_grid_apply and cleared.  Cost ~ Hm*Wm*4 bytes,
+// independent of the number of points.
+template <typename MapT>
+__global__ void __launch_bounds__(kBlock) k_grid_apply_scan(MapT* __restrict__ map, int C, CmParams cm,
+                                                            unsigned* __restrict__ cell_mask, long long ncell4) {
+    for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < ncell4; q += (long long)gridDim.x * kBlock) {
+        const uint4 m4 = reinterpret_cast<const uint4*>(cell_mask)[q];
+        if ((m4.x | m4.y | m4.z | m4.w) == 0u) continue;
+        const unsigned mm[4] = {m4.x, m4.y, m4.z, m4.w};
+        for (int j = 0; j < 4; ++j) {
+            const unsigned m = mm[j];
+            if (m == 0u) continue;
+            MapT* row = map + (q * 4 + j) * C;
+            for (int i = 0; i < C; ++i) {
+                if (m & (1u << i))
+                    for (int c = 0; c < C; ++c) row[c] = (MapT)((double)row[c] + cm.cm[c * C + i]);
+                if (m & (1u << (16 + i))) row[i] = (MapT)((double)row[i] + 2.0);
+            }
+        }
+        reinterpret_cast<uint4*>(cell_mask)[q] = make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
@@ -402,6 +434,31 @@ int launch_apply(const avl_grid* g, const double* cm_host, void* rows, int rows_
                            static_cast<float*>(rows), g->C, cm, g->cell_mask, g->touched, g->counter);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
+}
+
+int launch_apply_scan(const avl_grid* g, const double* cm_host, hipStream_t s) {
+    if (!cm_host) return avl::set_error(AVL_E_ARG, "cm_host is NULL");
+    CmParams cm;
+    memset(&cm, 0, sizeof(cm));
+    memcpy(cm.cm, cm_host, sizeof(double) * g->C * g->C);
+    const long long ncell4 = (long long)g->Hm * g->Wm / 4;
+    if (g->map_dtype == AVL_F64)
+        hipLaunchKernelGGL(k_grid_apply_scan<double>, dim3(2048), dim3(kBlock), 0, s, static_cast<double*>(g->map), g->C, cm, g->cell_mask, ncell4);
+    else
+        hipLaunchKernelGGL(k_grid_apply_scan<float>, dim3(2048), dim3(kBlock), 0, s, static_cast<float*>(g->map), g->C, cm, g->cell_mask, ncell4);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+// list (sparse) vs sweep (dense) apply: the sweep reads Hm*Wm*4 bytes whatever the cloud; the list costs a
+// returning atomic + an append per first touch.  AVL_APPLY_MODE=list|scan overrides (experiments).
+bool use_scan(const avl_grid* g, int n) {
+    static const char* mode = getenv("AVL_APPLY_MODE");
+    const long long cells = (long long)g->Hm * g->Wm;
+    if (cells % 4 != 0 || (reinterpret_cast<uintptr_t>(g->cell_mask) & 15)) return false;
+    if (mode && mode[0] == 'l') return false;
+    if (mode && mode[0] == 's') return true;
+    return (long long)n * 32 >= cells;
 }
 
 }  // namespace
@@ -522,14 +579,13 @@ extern "C" int avl_fused_frame(const avl_grid* g, const void* pts, int n, int dt
     hipStream_t s = avl::as_stream(stream);
     AVL_HIP_CHECK(hipMemsetAsync(g->counter, 0, 16, s));
     const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
-    if (src_kind == AVL_SRC_RGB)
-        hipLaunchKernelGGL(k_fused_vote<AVL_SRC_RGB>, grid, block, 0, s, pv, pp, gp, src, src_w, src_h, lut, g->cell_mask,
-                           g->touched, g->counter);
-    else
-        hipLaunchKernelGGL(k_fused_vote<AVL_SRC_CLASSMAP>, grid, block, 0, s, pv, pp, gp, src, src_w, src_h, lut,
-                           g->cell_mask, g->touched, g->counter);
+    const bool scan = use_scan(g, n);
+#define AVL_FV(SRC, LIST) hipLaunchKernelGGL((k_fused_vote<SRC, LIST>), grid, block, 0, s, pv, pp, gp, src, src_w, src_h, lut, g->cell_mask, g->touched, g->counter)
+    if (src_kind == AVL_SRC_RGB) { if (scan) AVL_FV(AVL_SRC_RGB, false); else AVL_FV(AVL_SRC_RGB, true); }
+    else { if (scan) AVL_FV(AVL_SRC_CLASSMAP, false); else AVL_FV(AVL_SRC_CLASSMAP, true); }
+#undef AVL_FV
     AVL_LAUNCH_CHECK();
-    return launch_apply(g, cm_host, nullptr, 0, s);
+    return scan ? launch_apply_scan(g, cm_host, s) : launch_apply(g, cm_host, nullptr, 0, s);
 }
 
 extern "C" int avl_colorize_labels(const uint8_t* labels, int lw, int lh, const uint8_t* palette_host, uint8_t* out,
