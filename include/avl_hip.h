@@ -163,7 +163,8 @@ typedef struct avl_seg_op {
     int32_t kind;            /* AVL_OP_*                                                        */
     int32_t dtype;           /* activation type of in/in2/out: AVL_BF16 or AVL_F32              */
     const void* in;          /* input activation (STEM: uint8 image; GEMV/GAP-out: fp32)       */
-    const void* in2;         /* GEMM: residual added before the ReLU, or NULL                   */
+    const void* in2;         /* GEMM: residual added before the ReLU, or NULL; GAP: fp32 scratch [256][C];
+                                DWCONV: 32 zero bytes (what a tap outside the image reads)          */
     void* out;
     const void* weight;      /* packed by the host, layout per kind (see network.py)            */
     const float* bias;       /* fp32 [out_c padded], or NULL                                    */

@@ -157,7 +157,8 @@ struct DwGeom {
 
 template <typename T>
 __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, const float* __restrict__ w,
-                                                    const float* __restrict__ bias, T* __restrict__ out, DwGeom g) {
+                                                    const float* __restrict__ bias, T* __restrict__ out, const T* __restrict__ zero,
+                                                    DwGeom g) {
     int b = blockIdx.x;
     const int cgrp = b % g.cgroups; b /= g.cgroups;
     const int bx = b % g.nbx; b /= g.nbx;
@@ -187,16 +188,22 @@ __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, c
         for (int gx = bx * g.band_w + cl; gx < gx1; gx += g.cl) {
             const int ox = rx + gx * g.dil;
             if (ox >= g.OW) break;
-            // all nine taps are fetched before any is used (clamped address, masked value): nine loads in flight.
-            // (Prefetching the next output's taps as well was measured slower: 216 VGPRs, 2 waves per SIMD.)
+            // all nine taps are fetched before any is used: nine loads in flight.  A tap outside the image reads a
+            // zero page instead (pointer select), so no per-element masking; tap addresses are the centre address
+            // plus nine wave-uniform offsets.  (The kernel was VALU-bound: ~270 vector ops per 16-byte output.)
             uint4 raw[9][NR];
-            float ok[9];
+            const T* centre = in + ((long long)(oy - g.pad + g.dil) * g.W + (ox - g.pad + g.dil)) * g.in_ld + c8 * 8;
+            bool rok[3], cok[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int iy = oy - g.pad + k * g.dil, ix = ox - g.pad + k * g.dil;
+                rok[k] = iy >= 0 && iy < g.H;
+                cok[k] = ix >= 0 && ix < g.W;
+            }
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int iy = oy - g.pad + (t / 3) * g.dil, ix = ox - g.pad + (t % 3) * g.dil;
-                ok[t] = (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) ? 1.f : 0.f;
-                const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
-                const uint4* src = reinterpret_cast<const uint4*>(in + ((long long)cy * g.W + cx) * g.in_ld + c8 * 8);
+                const long long off = ((long long)(t / 3 - 1) * g.dil * g.W + (t % 3 - 1) * g.dil) * g.in_ld;   // wave-uniform
+                const uint4* src = reinterpret_cast<const uint4*>((rok[t / 3] && cok[t % 3]) ? centre + off : zero);
                 raw[t][0] = src[0];
                 if constexpr (NR == 2) raw[t][1] = src[1];
             }
@@ -207,9 +214,8 @@ __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, c
             for (int t = 0; t < 9; ++t) {
                 float v[8];
                 Vec8<T>::load(reinterpret_cast<const T*>(&raw[t][0]), v);
-                const float m = ok[t];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = fmaf(v[i] * m, wt[t][i], acc[i]);
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(v[i], wt[t][i], acc[i]);
             }
             if (g.relu) {
 #pragma unroll
@@ -381,7 +387,8 @@ int launch_typed(const avl_seg_op& op, hipStream_t s) {
             g.nbx = (g.gw + g.band_w - 1) / g.band_w;
             while (g.band_h > 4 && combs * g.nbx * ((g.gh + g.band_h - 1) / g.band_h) < 512) g.band_h = (g.band_h + 1) / 2;
             g.nby = (g.gh + g.band_h - 1) / g.band_h;
-            hipLaunchKernelGGL(k_dwconv<T>, dim3((unsigned)(combs * g.nby * g.nbx)), dim3(kThreads), 0, s, in, w, op.bias, out, g);
+            hipLaunchKernelGGL(k_dwconv<T>, dim3((unsigned)(combs * g.nby * g.nbx)), dim3(kThreads), 0, s, in, w, op.bias, out,
+                               static_cast<const T*>(op.in2), g);
             break;
         }
         case AVL_OP_BILINEAR:
@@ -456,6 +463,7 @@ int validate_conv_op(const avl_seg_op& op) {
         }
         case AVL_OP_DWCONV:
             AVL_REQUIRE(op.weight && op.bias && op.out_c == op.in_c && op.ksize == 3 && op.stride == 1 && op.dil >= 1 && op.pad >= 0, "dwconv geometry");
+            AVL_REQUIRE(op.in2 && reinterpret_cast<uintptr_t>(op.in2) % 16 == 0, "dwconv needs in2 = a 32-byte zero page (taps outside the image read it)");
             AVL_REQUIRE(op.out_h == op.in_h + 2 * op.pad - 2 * op.dil && op.out_w == op.in_w + 2 * op.pad - 2 * op.dil, "dwconv output size");
             AVL_REQUIRE(op.in_c % (es == 2 ? 64 : 32) == 0, "dwconv channels %d not a multiple of one 128-byte line", op.in_c);
             break;

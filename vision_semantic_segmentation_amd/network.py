@@ -305,7 +305,8 @@ class SegNet(object):
         H, W = self.H, self.W
         dev = self.device
         self.image = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
-        self._keep.append(self.image)
+        self.zero_page = torch.zeros(64, dtype=torch.uint8, device=dev)          # what a depthwise tap outside the image reads
+        self._keep += [self.image, self.zero_page]
 
         # ---- stem: conv1 7x7 s2 + bn1 + relu (resnet.py:25-27), maxpool (:28)
         h2, w2 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
@@ -408,7 +409,7 @@ class SegNet(object):
             wd_, bd_ = self._dev(w.reshape(fc, 9).t().reshape(-1), torch.float32), self._dev(b, torch.float32)    # [tap][C]
             t = self._act(M, fc)
             self._spatial(p + ".depthwise_cnn", OP_DWCONV, feat, fhw, fc, t, fhw, fc, wd_, bd_, ksize=3, stride=1, pad=dil[k],
-                          dil=dil[k], groups=fc, relu=1)
+                          dil=dil[k], groups=fc, relu=1, in2=self.zero_page.data_ptr())
             w, b = fold_bn(st, p + ".pointwise_cnn.conv.weight", p + ".pointwise_cnn.bn")
             self._gemm(p + ".pointwise_cnn", t, fhw, fc, w, b, cat, dst_col=col)
             self._release(t)
@@ -457,7 +458,8 @@ class SegNet(object):
             w, b = fold_bn(st, p + ".depthwise_cnn.conv.weight", p + ".depthwise_cnn.bn")
             wd_, bd_ = self._dev(w.reshape(cin, 9).t().reshape(-1), torch.float32), self._dev(b, torch.float32)
             t = self._act(ohw[0] * ohw[1], cin)
-            self._spatial(p + ".depthwise_cnn", OP_DWCONV, x, hw, cin, t, ohw, cin, wd_, bd_, ksize=3, stride=1, pad=0, dil=1, groups=cin, relu=1)
+            self._spatial(p + ".depthwise_cnn", OP_DWCONV, x, hw, cin, t, ohw, cin, wd_, bd_, ksize=3, stride=1, pad=0, dil=1, groups=cin, relu=1,
+                          in2=self.zero_page.data_ptr())
             self._release(x)
             w, b = fold_bn(st, p + ".pointwise_cnn.conv.weight", p + ".pointwise_cnn.bn")
             y = self._act(ohw[0] * ohw[1], w.shape[0])
