@@ -134,6 +134,18 @@ int avl_colorize_labels(const uint8_t* labels, int lw, int lh, const uint8_t* pa
                         uint8_t* out, int out_w, int out_h, void* stream);
 
 
+/* ---- end-of-run rendering (src/renderer.py; called at src/mapping.py:332-334) ------------
+ * map [Hm][Wm][C] of map_dtype (AVL_F64 | AVL_F32); colors_host uint8[C][3]; out uint8[Hm][Wm][3]. */
+/* render_bev_map (renderer.py:32-59): colour of the arg-max channel, black where the channel sum is 0 */
+int avl_render_bev_map(const void* map, int map_dtype, int Hm, int Wm, int C, const uint8_t* colors_host,
+                       uint8_t* out, void* stream);
+/* render_bev_map_with_thresholds (renderer.py:131-172); priority_host int32[C] (NULL = 0..C-1, low to high),
+ * thresholds_host double[C] (NULL = 0.01 each) */
+int avl_render_bev_map_thresholds(const void* map, int map_dtype, int Hm, int Wm, int C, const uint8_t* colors_host,
+                                  const int32_t* priority_host, const double* thresholds_host, uint8_t* out, void* stream);
+/* apply_filter (renderer.py:175-189): 3x3 mean, kernel float32(1/9), BORDER_REFLECT_101; dst != src */
+int avl_grid_box_filter(const void* src, void* dst, int map_dtype, int Hm, int Wm, int C, void* stream);
+
 /* ---- a1-a5: segmentation forward (DeepLabV3+ / ResNeXt-50 OS8, eval mode) -------------------
  *
  * The reference builds the network from torch modules (src/semantic_segmentation.py:21-57,

@@ -231,8 +231,40 @@ def gen_network():
         print("blocks ok")
 
 
+def gen_render():
+    """src/renderer.py (numpy + scipy only) on a grid from the mapping fixtures plus hand-made corner cases."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_renderer", os.path.join(REF, "src", "renderer.py"))
+    rr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rr)
+    g = np.load(os.path.join(OUT, "mapping_C_velodyne_logcm.npz"))
+    grid = np.zeros((300, 260, 5))
+    idx = g["map2_idx"]
+    sel = (idx[:, 0] >= 850) & (idx[:, 0] < 1150) & (idx[:, 1] >= 870) & (idx[:, 1] < 1130)
+    grid[idx[sel, 0] - 850, idx[sel, 1] - 870] = g["map2_val"][sel]
+    rng = np.random.default_rng(7)
+    grid[5:60, 5:60] = rng.integers(-3, 4, size=(55, 55, 5))          # ties, negatives, exact zero sums
+    grid[70:75, 70:75] = 0.0
+    grid[80, 80] = [1.0, -1.0, 0.0, 0.0, 0.0]                          # non-zero cell whose sum is 0 -> black
+    grid[81, 81] = [0.2, 0.2, 0.2, 0.2, 0.2]
+    colors = np.array(mo.LABEL_COLORS)
+    a = rr.render_bev_map(grid, colors)
+    prio = [3, 4, 0, 2, 1]
+    thr = [0.1, 0.1, 0.5, 0.20, 0.05]
+    with np.errstate(all="ignore"):
+        b = rr.render_bev_map_with_thresholds(grid, colors, priority=prio, thresholds=thr)
+        c = rr.render_bev_map_with_thresholds(grid, colors)
+    np.savez_compressed(os.path.join(OUT, "render.npz"), grid=grid, colors=colors, bev=a, priority=np.array(prio),
+                        thresholds=np.array(thr), bev_thr=b, bev_thr_default=c)
+    print("render", a.shape, int((a.sum(axis=2) > 0).sum()), int((b.sum(axis=2) > 0).sum()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "render":
+        gen_render()
+        sys.exit(0)
     ref_mapping, ref_camera = import_reference_mapping()
     gen_mapping(ref_mapping, ref_camera)
     gen_network()
+    gen_render()

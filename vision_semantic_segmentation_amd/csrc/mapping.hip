@@ -353,6 +353,75 @@ __global__ void __launch_bounds__(kBlock) k_grid_apply_scan(MapT* __restrict__ m
     }
 }
 
+// ================================================================ end-of-run rendering (src/renderer.py), SURVEY 8f row 3
+struct RenderParams {
+    unsigned char colors[AVL_MAX_MAP_CLASSES * 3];
+    int priority[AVL_MAX_MAP_CLASSES];
+    double thresholds[AVL_MAX_MAP_CLASSES];
+};
+
+// render_bev_map (renderer.py:32-59): colour of np.argmax (first maximum wins), black where the channel sum is 0
+template <typename MapT>
+__global__ void __launch_bounds__(kBlock) k_render_bev(const MapT* __restrict__ map, long long ncell, int C, RenderParams rp,
+                                                       unsigned char* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= ncell) return;
+    const MapT* row = map + i * C;
+    double best = (double)row[0], sum = 0.0;
+    int bi = 0;
+    for (int c = 0; c < C; ++c) {
+        const double v = (double)row[c];
+        sum = sum + v;                                            // np.sum over 5 contiguous values: sequential from 0
+        if (c > 0 && (v > best || (v != v && best == best))) { best = v; bi = c; }
+    }
+    unsigned char r = rp.colors[3 * bi], g = rp.colors[3 * bi + 1], b = rp.colors[3 * bi + 2];
+    if (sum == 0.0) r = g = b = 0;
+    out[3 * i] = r; out[3 * i + 1] = g; out[3 * i + 2] = b;
+}
+
+// render_bev_map_with_thresholds (renderer.py:131-172): later priorities overwrite earlier ones
+template <typename MapT>
+__global__ void __launch_bounds__(kBlock) k_render_thresholds(const MapT* __restrict__ map, long long ncell, int C, RenderParams rp,
+                                                              unsigned char* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= ncell) return;
+    const MapT* row = map + i * C;
+    MapT s = (MapT)0;
+    for (int c = 0; c < C; ++c) s = s + row[c];
+    unsigned char r = 0, g = 0, b = 0;
+    if (s != (MapT)0) {
+        for (int k = 0; k < C; ++k) {
+            const int ch = rp.priority[k];
+            const MapT pn = row[ch] / s;                          // np.divide(map, channel_sum), same element type as the map
+            if ((double)pn >= rp.thresholds[k]) { r = rp.colors[3 * ch]; g = rp.colors[3 * ch + 1]; b = rp.colors[3 * ch + 2]; }
+        }
+    }
+    out[3 * i] = r; out[3 * i + 1] = g; out[3 * i + 2] = b;
+}
+
+// apply_filter (renderer.py:175-189): cv2.filter2D with ones(3,3,float32)/9, BORDER_REFLECT_101, double accumulation
+template <typename MapT>
+__global__ void __launch_bounds__(kBlock) k_box_filter3(const MapT* __restrict__ src, MapT* __restrict__ dst, int Hm, int Wm, int C) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long total = (long long)Hm * Wm * C;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const long long cell = i / C;
+    const int x = (int)(cell % Wm), y = (int)(cell / Wm);
+    const double k = (double)(1.0f / 9.0f);
+    double acc = 0.0;
+    for (int dy = -1; dy <= 1; ++dy) {
+        int yy = y + dy;
+        yy = yy < 0 ? -yy : (yy >= Hm ? 2 * Hm - 2 - yy : yy);
+        for (int dx = -1; dx <= 1; ++dx) {
+            int xx = x + dx;
+            xx = xx < 0 ? -xx : (xx >= Wm ? 2 * Wm - 2 - xx : xx);
+            acc = acc + k * (double)src[((long long)yy * Wm + xx) * C + c];
+        }
+    }
+    dst[i] = (MapT)acc;
+}
+
 __global__ void __launch_bounds__(kBlock) k_colorize(const unsigned char* __restrict__ labels, int lw, int lh,
                                                      const unsigned* __restrict__ pal_packed_dummy, LutParams pal,
                                                      unsigned char* __restrict__ out, int out_w, int out_h) {
@@ -598,6 +667,64 @@ extern "C" int avl_colorize_labels(const uint8_t* labels, int lw, int lh, const 
     const long long total = (long long)out_w * out_h;
     hipLaunchKernelGGL(k_colorize, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, avl::as_stream(stream),
                        labels, lw, lh, nullptr, pal, out, out_w, out_h);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+// ---------------------------------------------------------------------------------------- rendering
+namespace {
+int fill_render(RenderParams& rp, int C, const uint8_t* colors, const int32_t* priority, const double* thresholds) {
+    if (C <= 0 || C > AVL_MAX_MAP_CLASSES) return avl::set_error(AVL_E_ARG, "C = %d", C);
+    if (!colors) return avl::set_error(AVL_E_ARG, "colors_host is NULL");
+    memset(&rp, 0, sizeof(rp));
+    memcpy(rp.colors, colors, 3 * C);
+    for (int k = 0; k < C; ++k) {
+        rp.priority[k] = priority ? priority[k] : k;
+        if (rp.priority[k] < 0 || rp.priority[k] >= C) return avl::set_error(AVL_E_ARG, "priority[%d] = %d", k, rp.priority[k]);
+        rp.thresholds[k] = thresholds ? thresholds[k] : 0.01;
+    }
+    return AVL_OK;
+}
+}  // namespace
+
+extern "C" int avl_render_bev_map(const void* map, int map_dtype, int Hm, int Wm, int C, const uint8_t* colors_host, uint8_t* out,
+                                  void* stream) {
+    RenderParams rp;
+    int rc;
+    if ((rc = fill_render(rp, C, colors_host, nullptr, nullptr))) return rc;
+    AVL_REQUIRE(map && out && Hm > 0 && Wm > 0, "bad map / out");
+    AVL_REQUIRE(map_dtype == AVL_F64 || map_dtype == AVL_F32, "map dtype %d", map_dtype);
+    const long long n = (long long)Hm * Wm;
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    if (map_dtype == AVL_F64) hipLaunchKernelGGL(k_render_bev<double>, grid, block, 0, avl::as_stream(stream), static_cast<const double*>(map), n, C, rp, out);
+    else hipLaunchKernelGGL(k_render_bev<float>, grid, block, 0, avl::as_stream(stream), static_cast<const float*>(map), n, C, rp, out);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+extern "C" int avl_render_bev_map_thresholds(const void* map, int map_dtype, int Hm, int Wm, int C, const uint8_t* colors_host,
+                                             const int32_t* priority_host, const double* thresholds_host, uint8_t* out, void* stream) {
+    RenderParams rp;
+    int rc;
+    if ((rc = fill_render(rp, C, colors_host, priority_host, thresholds_host))) return rc;
+    AVL_REQUIRE(map && out && Hm > 0 && Wm > 0, "bad map / out");
+    AVL_REQUIRE(map_dtype == AVL_F64 || map_dtype == AVL_F32, "map dtype %d", map_dtype);
+    const long long n = (long long)Hm * Wm;
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    if (map_dtype == AVL_F64) hipLaunchKernelGGL(k_render_thresholds<double>, grid, block, 0, avl::as_stream(stream), static_cast<const double*>(map), n, C, rp, out);
+    else hipLaunchKernelGGL(k_render_thresholds<float>, grid, block, 0, avl::as_stream(stream), static_cast<const float*>(map), n, C, rp, out);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+extern "C" int avl_grid_box_filter(const void* src, void* dst, int map_dtype, int Hm, int Wm, int C, void* stream) {
+    AVL_REQUIRE(src && dst && src != dst, "box filter needs distinct src and dst");
+    AVL_REQUIRE(Hm > 1 && Wm > 1 && C > 0, "grid %dx%dx%d", Hm, Wm, C);
+    AVL_REQUIRE(map_dtype == AVL_F64 || map_dtype == AVL_F32, "map dtype %d", map_dtype);
+    const long long n = (long long)Hm * Wm * C;
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    if (map_dtype == AVL_F64) hipLaunchKernelGGL(k_box_filter3<double>, grid, block, 0, avl::as_stream(stream), static_cast<const double*>(src), static_cast<double*>(dst), Hm, Wm, C);
+    else hipLaunchKernelGGL(k_box_filter3<float>, grid, block, 0, avl::as_stream(stream), static_cast<const float*>(src), static_cast<float*>(dst), Hm, Wm, C);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
