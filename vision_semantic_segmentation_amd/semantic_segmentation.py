@@ -77,20 +77,3 @@ class SemanticSegmentation(object):
             v = image.reshape(out_h, fy, out_w, fx, -1).astype(np.float32).mean(axis=(1, 3))
             return np.clip(np.rint(v), 0, 255).astype(np.uint8)
         raise NotImplementedError("INTER_AREA for non-integer scale factors is not built yet")
-
-
-def smoke_segmentation(device):
-    """One small forward on the GPU against the torch-CPU oracle (called by __graft_entry__.smoke)."""
-    from oracle import network_oracle as no
-    from .config import get_network_cfg_defaults
-    cfg = get_network_cfg_defaults()
-    cfg.MODEL.PRECISION = "f32"
-    seg = SemanticSegmentation(cfg, device=device)
-    rng = np.random.default_rng(0)
-    img = rng.integers(0, 256, size=(96, 128, 3), dtype=np.uint8)
-    got = seg.logits(img).cpu()
-    ref = no.forward_logits(seg.state, img)[0]
-    err = float((got - ref).abs().max() / ref.abs().max())
-    assert got.shape == ref.shape and err < 1e-3, "segmentation logits differ from the oracle: rel err %g" % err
-    agree = float((got.argmax(0) == ref.argmax(0)).float().mean())
-    print("smoke: segmentation f32 logits max rel err %.2e, argmax agreement %.4f" % (err, agree))
