@@ -140,7 +140,7 @@ def main():
         max_dlogodds = float(np.max(np.abs(sm2.map - grid)))
 
         cpu_baseline = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # the CPU baseline is reported at N = 1 only
             cpu_baseline = cpu_baseline_leg(state, image.cpu().numpy(), pcd64, sem, cam, ocfg, t_map)
 
         result = {

@@ -258,9 +258,21 @@ template <typename T>
 __global__ void __launch_bounds__(kThreads) k_gap_partial(const T* __restrict__ in, int M, int C, int in_ld,
                                                          float* __restrict__ partial) {
     const int c8n = C / 8;
+    const int G = gridDim.x;
     for (int c8 = threadIdx.x; c8 < c8n; c8 += kThreads) {
         float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int r = blockIdx.x; r < M; r += gridDim.x) {
+        int r = blockIdx.x;
+        // four rows in flight per lane (a dependent one-load-at-a-time loop left the kernel latency-bound)
+        for (; r + 3 * G < M; r += 4 * G) {
+            float v0[8], v1[8], v2[8], v3[8];
+            Vec8<T>::load(in + (long long)r * in_ld + c8 * 8, v0);
+            Vec8<T>::load(in + (long long)(r + G) * in_ld + c8 * 8, v1);
+            Vec8<T>::load(in + (long long)(r + 2 * G) * in_ld + c8 * 8, v2);
+            Vec8<T>::load(in + (long long)(r + 3 * G) * in_ld + c8 * 8, v3);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += (v0[i] + v1[i]) + (v2[i] + v3[i]);
+        }
+        for (; r < M; r += G) {
             float v[8];
             Vec8<T>::load(in + (long long)r * in_ld + c8 * 8, v);
 #pragma unroll

@@ -102,15 +102,19 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs p) {
     for (int st = half; st < nsub; st += 2) {
         const int sy = st >> 1, sx = (st & 1) * 16 + fr;        // output pixel (tile-local) of this lane
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // all nine tap fragments are requested before the first MFMA: the LDS latency is paid once per sub-tile,
+        // not once per tap (the read -> 2 MFMA -> read chain left the matrix pipe idle ~2/3 of the time)
+        bf16x8 a[9];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
+        for (int t = 0; t < 9; ++t) {
+            const int pix = (sy * s + (t / 3) * d) * in_tw + sx * s + (t % 3) * d;
+            a[t] = *reinterpret_cast<const bf16x8*>(lds + pix * 128 + ((chunk_in ^ (pix & 7)) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int pix = (sy * s + ky * d) * in_tw + sx * s + kx * d;
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(lds + pix * 128 + ((chunk_in ^ (pix & 7)) << 4));
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ky * 3 + kx], a, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ky * 3 + kx], a, acc1, 0, 0, 0);
-            }
+        for (int t = 0; t < 9; ++t) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t], a[t], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][t], a[t], acc1, 0, 0, 0);
         }
         const int oy = oy0 + sy, ox = ox0 + sx;
         if (oy < p.OH && ox < p.OW) {
