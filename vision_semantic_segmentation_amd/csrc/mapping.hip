@@ -527,7 +527,7 @@ bool use_scan(const avl_grid* g, int n) {
     if (cells % 4 != 0 || (reinterpret_cast<uintptr_t>(g->cell_mask) & 15)) return false;
     if (mode && mode[0] == 'l') return false;
     if (mode && mode[0] == 's') return true;
-    return (long long)n * 32 >= cells;
+    return (long long)n * 128 >= cells;      // measured: sweep wins at 120 k points on 4 M cells (25 vs 36 us) and 1 M on 16 M (73 vs 213 us)
 }
 
 }  // namespace

@@ -45,9 +45,21 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_DBL_CACHE = {}
+
+
 def _dbl(a):
+    """float64 ctypes array of a small host matrix (P, T, CM); memoised on the bytes -- the same few matrices are
+    passed every frame and building a ctypes array element by element costs more than the kernel launch."""
     a = np.ascontiguousarray(a, dtype=np.float64).ravel()
-    return (C.c_double * a.size)(*a.tolist())
+    key = a.tobytes()
+    hit = _DBL_CACHE.get(key)
+    if hit is None:
+        if len(_DBL_CACHE) > 256:
+            _DBL_CACHE.clear()
+        hit = (C.c_double * a.size).from_buffer_copy(key)
+        _DBL_CACHE[key] = hit
+    return hit
 
 
 class DeviceGrid(object):
@@ -360,8 +372,7 @@ class SemanticMapping(object):
             sh, sw = int(semantic.shape[0]), int(semantic.shape[1])
             ih, iw = (sh, sw) if image_size is None else (int(image_size[0]), int(image_size[1]))
             kind = _lib.AVL_SRC_CLASSMAP
-            lut_np = vote_lut(net_palette, self.label_colors)
-            lut = (C.c_uint32 * 256)(*lut_np.tolist())
+            lut = self._lut_host(net_palette)
         semantic = semantic.contiguous()
         s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
         rc = _lib.lib().avl_fused_frame(C.byref(gs), pts, n, dtype, pstride, cstride, P, Tc, float(self.pcd_range_max),
@@ -482,7 +493,17 @@ class SemanticMapping(object):
 
     def _colors_host(self):
         c = np.ascontiguousarray(self.label_colors, dtype=np.uint8).ravel()
-        return (C.c_uint8 * c.size)(*c.tolist())
+        key = c.tobytes()
+        if getattr(self, "_colors_key", None) != key:
+            self._colors_key, self._colors_c = key, (C.c_uint8 * c.size).from_buffer_copy(key)
+        return self._colors_c
+
+    def _lut_host(self, net_palette):
+        key = (np.asarray(net_palette, dtype=np.uint8).tobytes(), np.ascontiguousarray(self.label_colors, dtype=np.uint8).tobytes())
+        if getattr(self, "_lut_key", None) != key:
+            lut_np = vote_lut(net_palette, self.label_colors)
+            self._lut_key, self._lut_c = key, (C.c_uint32 * 256).from_buffer_copy(lut_np.astype(np.uint32).tobytes())
+        return self._lut_c
 
     def _bonus_classes(self):
         """bit i set when class i is a "lane" class and USE_INTENSITY is on (mapping.py:427-431)."""
