@@ -134,6 +134,13 @@ int avl_colorize_labels(const uint8_t* labels, int lw, int lh, const uint8_t* pa
                         uint8_t* out, int out_w, int out_h, void* stream);
 
 
+/* ---- the semantic point cloud mapping() publishes (src/mapping.py:316-317) ---------------
+ * create_point_cloud (src/utils/utils_ros.py:31-59) without its per-point struct.pack loop: record k (16 bytes,
+ * point_step 16) = float32 x,y,z of pcd[0:3][k] and uint32 rgba = r | g<<8 | b<<16 | 255<<24 of label[:,k].
+ * pcd double[4][ld], label uint8[3][ld] as avl_project_pcd returns them; count = m_host or *m_dev. */
+int avl_pack_semantic_cloud(const double* pcd, const uint8_t* label, int64_t ld, int m_host, const int32_t* m_dev,
+                            void* out_records, void* stream);
+
 /* ---- end-of-run rendering (src/renderer.py; called at src/mapping.py:332-334) ------------
  * map [Hm][Wm][C] of map_dtype (AVL_F64 | AVL_F32); colors_host uint8[C][3]; out uint8[Hm][Wm][3]. */
 /* render_bev_map (renderer.py:32-59): colour of the arg-max channel, black where the channel sum is 0 */

@@ -671,6 +671,33 @@ extern "C" int avl_colorize_labels(const uint8_t* labels, int lw, int lh, const 
     return AVL_OK;
 }
 
+// ---------------------------------------------------------------------------------------- semantic point cloud
+namespace {
+// create_point_cloud (src/utils/utils_ros.py:31-59): one PointCloud2 record per point, fields x,y,z FLOAT32 at
+// offsets 0/4/8 and rgba UINT32 at 12 = struct.pack('BBBB', r, g, b, 255) read back as a little-endian 'I'.
+__global__ void __launch_bounds__(kBlock) k_pack_cloud(const double* __restrict__ pcd, const unsigned char* __restrict__ label,
+                                                       long long ld, int m_host, const int* __restrict__ m_dev, uint4* __restrict__ out) {
+    const int m = m_dev ? min(*m_dev, m_host) : m_host;
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= m) return;
+    const float x = (float)pcd[k], y = (float)pcd[ld + k], z = (float)pcd[2 * ld + k];
+    const unsigned rgba = (unsigned)label[k] | ((unsigned)label[ld + k] << 8) | ((unsigned)label[2 * ld + k] << 16) | (255u << 24);
+    out[k] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), rgba);
+}
+}  // namespace
+
+extern "C" int avl_pack_semantic_cloud(const double* pcd, const uint8_t* label, int64_t ld, int m_host, const int32_t* m_dev,
+                                       void* out_records, void* stream) {
+    AVL_REQUIRE(m_host >= 0, "m = %d", m_host);
+    if (m_host == 0) return AVL_OK;
+    AVL_REQUIRE(pcd && label && out_records && ld >= m_host, "bad buffers");
+    AVL_REQUIRE(reinterpret_cast<uintptr_t>(out_records) % 16 == 0, "out_records must be 16-byte aligned");
+    hipLaunchKernelGGL(k_pack_cloud, dim3((m_host + kBlock - 1) / kBlock), dim3(kBlock), 0, avl::as_stream(stream), pcd, label,
+                       (long long)ld, m_host, m_dev, static_cast<uint4*>(out_records));
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
 // ---------------------------------------------------------------------------------------- rendering
 namespace {
 int fill_render(RenderParams& rp, int C, const uint8_t* colors, const int32_t* priority, const double* thresholds) {

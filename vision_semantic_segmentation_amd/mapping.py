@@ -412,6 +412,19 @@ class SemanticMapping(object):
         _lib.check(rc, "avl_project_pcd")
         return out_pcd, out_label, count[:1]
 
+    def semantic_cloud_device(self, pcd, pcd_frame_id, image, pose, camera_calibration):
+        """The semantic point cloud mapping() publishes (mapping.py:314-317): project_pcd followed by
+        create_point_cloud (utils_ros.py:31-59), both on the GPU.  Returns (records uint8[M,16] CUDA tensor in
+        PointCloud2 layout x,y,z float32 + rgba uint32, M)."""
+        out_pcd, out_label, count = self.project_pcd_device(pcd, pcd_frame_id, image, pose, camera_calibration)
+        n = int(out_pcd.shape[1])
+        rec = torch.empty((max(n, 1), 16), dtype=torch.uint8, device=self.device)
+        s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(_lib.lib().avl_pack_semantic_cloud(_ptr(out_pcd), _ptr(out_label), n, n, _ptr(count), _ptr(rec), s),
+                   "avl_pack_semantic_cloud")
+        m = int(count.item())
+        return rec[:m], m
+
     def update_map(self, map, pcd, label):
         """mapping.py:391-444.  ``map`` may be
           * a CUDA tensor [Hm,Wm,C] (float64/float32): updated in place on the GPU and returned;

@@ -115,3 +115,22 @@ def get_transform_from_pose(pose, tf_ros=None):
     M = np.identity(4)
     M[:3, 3] = t
     return np.dot(M, quaternion_matrix(q))
+
+
+def create_point_cloud(xyz, rgb=None, frame_id="world"):
+    """utils_ros.py:31-59 without ROS: returns a dict shaped like sensor_msgs/PointCloud2 (header.frame_id, height,
+    width, fields, point_step, row_step, data bytes).  xyz: n x 3, rgb: n x 3 (or None).  Vectorised host version;
+    SemanticMapping.semantic_cloud_device() is the GPU one (avl_pack_semantic_cloud)."""
+    xyz = np.asarray(xyz)
+    n = xyz.shape[0]
+    if rgb is None:
+        rec = np.zeros(n, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
+        fields = [("x", 0, "FLOAT32"), ("y", 4, "FLOAT32"), ("z", 8, "FLOAT32")]
+    else:
+        rgb = np.asarray(rgb).astype(np.int64)
+        rec = np.zeros(n, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgba", "<u4")])
+        rec["rgba"] = (rgb[:, 0] & 255) | ((rgb[:, 1] & 255) << 8) | ((rgb[:, 2] & 255) << 16) | (255 << 24)
+        fields = [("x", 0, "FLOAT32"), ("y", 4, "FLOAT32"), ("z", 8, "FLOAT32"), ("rgba", 12, "UINT32")]
+    rec["x"], rec["y"], rec["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    return {"header": Header(frame_id=frame_id), "height": 1, "width": n, "fields": fields, "is_bigendian": False,
+            "point_step": rec.dtype.itemsize, "row_step": rec.dtype.itemsize * n, "data": rec.tobytes(), "is_dense": True}
