@@ -205,8 +205,10 @@ typedef struct avl_seg_plan avl_seg_plan;
 /* copies the op list, validates shapes/strides/allocated rows against what the kernels read */
 int avl_seg_plan_create(const avl_seg_op* ops_host, int n_ops, avl_seg_plan** out_plan);
 void avl_seg_plan_destroy(avl_seg_plan* plan);
-/* launches every op on `stream` (no sync) */
+/* launches every op on `stream` (no sync); after avl_seg_plan_capture: one hipGraphLaunch */
 int avl_seg_plan_run(avl_seg_plan* plan, void* stream);
+/* records the op list into a hipGraph (stream capture on `stream`, non-NULL; run the plan once before) */
+int avl_seg_plan_capture(avl_seg_plan* plan, void* stream);
 /* same, with a hipEvent pair around every op; blocks until done; ms_host[n_ops] = op durations.
  * flops_host / bytes_host (either may be NULL) receive each op's algorithmic flops and bytes. */
 int avl_seg_plan_profile(avl_seg_plan* plan, void* stream, float* ms_host, double* flops_host, double* bytes_host);

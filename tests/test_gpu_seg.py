@@ -110,3 +110,21 @@ def test_node_callback_and_fused_mapping(state, cuda_device):
     b.pcd, b.pcd_frame_id = pcd, "velodyne"
     b.mapping(colour, None, cam)
     assert torch.equal(a.map_dev, b.map_dev) and float(a.map_dev.abs().sum()) > 0
+
+
+def test_hipgraph_replay_is_identical(state, cuda_device):
+    """avl_seg_plan_capture: the captured plan replays to bit-identical logits, frame after frame."""
+    import torch
+    from vision_semantic_segmentation_amd.network import SegNet
+    net = SegNet(state, 96, 128, precision="bf16", device=cuda_device)
+    rng = np.random.default_rng(5)
+    a = torch.from_numpy(rng.integers(0, 256, size=(96, 128, 3), dtype=np.uint8)).to(cuda_device)
+    b = torch.from_numpy(rng.integers(0, 256, size=(96, 128, 3), dtype=np.uint8)).to(cuda_device)
+    net.forward(a)
+    la = net.logits.clone()
+    net.forward(b)
+    lb = net.logits.clone()
+    net.capture_graph()
+    for img, ref in ((a, la), (b, lb), (a, la)):
+        net.forward(img)
+        assert torch.equal(net.logits, ref)

@@ -57,3 +57,19 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
 print("plan run: %.3f ms/frame = %.1f frames/s, %.1f TFLOP/s" % (ms, 1e3 / ms, fl / ms / 1e9))
+import time
+ref = net.labels.clone()
+net.capture_graph()
+for _ in range(3):
+    net.forward()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+e0.record()
+for _ in range(10):
+    net.forward()
+e1.record()
+host = (time.perf_counter() - t0) / 10
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+print("hipGraph replay: %.3f ms/frame = %.1f frames/s (host %.1f us per forward), labels identical: %s"
+      % (ms, 1e3 / ms, host * 1e6, bool(torch.equal(ref, net.labels))))

@@ -96,6 +96,7 @@ def get_network_cfg_defaults():
     # build-specific (not in the reference): activation precision of the HIP conv stack
     C.MODEL.PRECISION = "bf16"     # "bf16" (MFMA bf16, fp32 accumulate) or "f32" (fp32-input MFMA)
     C.MODEL.SEED = 0               # seed of the random weights used when MODEL.WEIGHT == ""
+    C.MODEL.HIP_GRAPH = True       # replay the ~90-kernel plan as one hipGraph launch per frame
     return C
 
 

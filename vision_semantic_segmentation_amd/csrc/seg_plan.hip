@@ -6,6 +6,8 @@
 struct avl_seg_plan {
     std::vector<avl_seg_op> ops;
     std::vector<hipEvent_t> ev;   // 2 per op, created lazily by avl_seg_plan_profile
+    hipGraph_t graph = nullptr;   // the op list captured once (avl_seg_plan_capture) ...
+    hipGraphExec_t exec = nullptr;  // ... and replayed by avl_seg_plan_run with one launch
 };
 
 namespace avl {
@@ -86,15 +88,45 @@ extern "C" int avl_seg_plan_create(const avl_seg_op* ops_host, int n_ops, avl_se
 
 extern "C" void avl_seg_plan_destroy(avl_seg_plan* plan) {
     if (!plan) return;
+    if (plan->exec) (void)hipGraphExecDestroy(plan->exec);
+    if (plan->graph) (void)hipGraphDestroy(plan->graph);
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
 }
 
 extern "C" int avl_seg_plan_num_ops(const avl_seg_plan* plan) { return plan ? (int)plan->ops.size() : 0; }
 
+// Captures the plan's ~90 launches into a hipGraph on `stream` (which must not be the legacy NULL stream).  The plan
+// has to have run once before (kernel attributes are set on first launch, which is not allowed during capture).
+// Every buffer is fixed at plan creation, so the graph stays valid for the plan's life; avl_seg_plan_run then
+// replays it with a single hipGraphLaunch (host cost ~15 us instead of ~90 launches).
+extern "C" int avl_seg_plan_capture(avl_seg_plan* plan, void* stream) {
+    AVL_REQUIRE(plan && stream, "avl_seg_plan_capture needs a plan and a non-NULL stream");
+    hipStream_t s = avl::as_stream(stream);
+    if (plan->exec) { (void)hipGraphExecDestroy(plan->exec); plan->exec = nullptr; }
+    if (plan->graph) { (void)hipGraphDestroy(plan->graph); plan->graph = nullptr; }
+    AVL_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = AVL_OK;
+    for (const avl_seg_op& op : plan->ops) {
+        rc = avl::launch(op, s);
+        if (rc) break;
+    }
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return avl::set_error(AVL_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    plan->graph = g;
+    AVL_HIP_CHECK(hipGraphInstantiate(&plan->exec, plan->graph, nullptr, nullptr, 0));
+    return AVL_OK;
+}
+
 extern "C" int avl_seg_plan_run(avl_seg_plan* plan, void* stream) {
     AVL_REQUIRE(plan, "plan is NULL");
     hipStream_t s = avl::as_stream(stream);
+    if (plan->exec) {
+        AVL_HIP_CHECK(hipGraphLaunch(plan->exec, s));
+        return AVL_OK;
+    }
     for (const avl_seg_op& op : plan->ops) {
         int rc = avl::launch(op, s);
         if (rc) return rc;

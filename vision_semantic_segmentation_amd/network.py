@@ -49,6 +49,7 @@ _lib._register_seg({
     "avl_seg_plan_create": (_i, [C.POINTER(AvlSegOp), _i, C.POINTER(C.c_void_p)]),
     "avl_seg_plan_destroy": (None, [_vp]),
     "avl_seg_plan_run": (_i, [_vp, _vp]),
+    "avl_seg_plan_capture": (_i, [_vp, _vp]),
     "avl_seg_plan_profile": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "avl_seg_plan_num_ops": (_i, [_vp]),
 })
@@ -500,6 +501,18 @@ class SegNet(object):
         s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
         _lib.check(_lib.lib().avl_seg_plan_run(self._plan, C.c_void_p(s)), "avl_seg_plan_run")
         return self.labels
+
+    def capture_graph(self):
+        """Record the plan into a hipGraph (one launch per forward afterwards).  Runs the plan once first, on a
+        side stream (stream capture is not allowed on the legacy default stream)."""
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            _lib.check(_lib.lib().avl_seg_plan_run(self._plan, C.c_void_p(side.cuda_stream)), "avl_seg_plan_run")
+            side.synchronize()
+            _lib.check(_lib.lib().avl_seg_plan_capture(self._plan, C.c_void_p(side.cuda_stream)), "avl_seg_plan_capture")
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        self.graphed = True
 
     def profile(self):
         """HIP-event time of every op (ms), plus its algorithmic flops and bytes -> list of dicts."""

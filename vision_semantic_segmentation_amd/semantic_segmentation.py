@@ -45,8 +45,10 @@ class SemanticSegmentation(object):
         """The compiled plan for an h x w input (built on first use, kept per size)."""
         key = (int(h), int(w))
         if key not in self._nets:
-            self._nets[key] = SegNet(self.state, key[0], key[1], precision=self.precision, device=self.device,
-                                     num_classes=self.num_classes)
+            net = SegNet(self.state, key[0], key[1], precision=self.precision, device=self.device, num_classes=self.num_classes)
+            if getattr(self.cfg.MODEL, "HIP_GRAPH", True):
+                net.capture_graph()
+            self._nets[key] = net
         return self._nets[key]
 
     def segmentation_device(self, image_in):
