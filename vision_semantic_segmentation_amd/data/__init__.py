@@ -1,0 +1,1 @@
+"""Host-side tables (confusion matrix) consumed by the grid-update kernel."""

@@ -265,27 +265,25 @@ class SemanticMapping(object):
             self.pcd_header_queue.append(msg.header)
             self.pcd_frame_id = msg.header.frame_id
 
+    @staticmethod
+    def _nearest_in_queue(stamps, target_stamp):
+        """Index selection shared by update_pcd / update_pose (mapping.py:185-219, :238-259): walk the queue for the first
+        pair that brackets `target_stamp` strictly and keep the closer of the two (the earlier one on a tie); the
+        queue is then trimmed from the earlier element of that pair.  Without a bracketing pair: the latest element,
+        and the queue shrinks to it.  Returns (index of the pick, index to trim from)."""
+        for i in range(len(stamps) - 1):
+            if stamps[i + 1] > target_stamp and stamps[i] < target_stamp:
+                later_is_closer = (target_stamp - stamps[i]) > (stamps[i + 1] - target_stamp)
+                return (i + 1 if later_is_closer else i), i
+        return len(stamps) - 1, len(stamps) - 1
+
     def update_pcd(self, target_stamp):
         """Closest point cloud w.r.t. target_stamp (mapping.py:185-219)."""
-        for i in range(len(self.pcd_header_queue) - 1):
-            if self.pcd_header_queue[i + 1].stamp > target_stamp:
-                if self.pcd_header_queue[i].stamp < target_stamp:
-                    diff_2 = self.pcd_header_queue[i + 1].stamp - target_stamp
-                    diff_1 = target_stamp - self.pcd_header_queue[i].stamp
-                    if diff_1 > diff_2:
-                        header = self.pcd_header_queue[i + 1]
-                        pcd = self.pcd_queue[i + 1]
-                    else:
-                        header = self.pcd_header_queue[i]
-                        pcd = self.pcd_queue[i]
-                    self.pcd_header_queue = self.pcd_header_queue[i::]
-                    self.pcd_queue = self.pcd_queue[i::]
-                    return pcd, header.stamp
-        header = self.pcd_header_queue[-1]
-        pcd = self.pcd_queue[-1]
-        self.pcd_header_queue = self.pcd_header_queue[-1::]
-        self.pcd_queue = self.pcd_queue[-1::]
-        return pcd, header.stamp
+        pick, keep = self._nearest_in_queue([h.stamp for h in self.pcd_header_queue], target_stamp)
+        pcd, stamp = self.pcd_queue[pick], self.pcd_header_queue[pick].stamp
+        self.pcd_header_queue = self.pcd_header_queue[keep:]
+        self.pcd_queue = self.pcd_queue[keep:]
+        return pcd, stamp
 
     def pose_callback(self, msg):
         """mapping.py:221-226"""
@@ -296,19 +294,9 @@ class SemanticMapping(object):
 
     def update_pose(self, target_stamp):
         """Closest pose w.r.t. target_stamp (mapping.py:238-259)."""
-        for i in range(len(self.pose_queue) - 1):
-            if self.pose_queue[i + 1].header.stamp > target_stamp:
-                if self.pose_queue[i].header.stamp < target_stamp:
-                    diff_2 = self.pose_queue[i + 1].header.stamp - target_stamp
-                    diff_1 = target_stamp - self.pose_queue[i].header.stamp
-                    if diff_1 > diff_2:
-                        msg = self.pose_queue[i + 1]
-                    else:
-                        msg = self.pose_queue[i]
-                    self.pose_queue = self.pose_queue[i::]
-                    return msg.pose, msg.header.stamp
-        msg = self.pose_queue[-1]
-        self.pose_queue = self.pose_queue[-1::]
+        pick, keep = self._nearest_in_queue([m.header.stamp for m in self.pose_queue], target_stamp)
+        msg = self.pose_queue[pick]
+        self.pose_queue = self.pose_queue[keep:]
         return msg.pose, msg.header.stamp
 
     def image_callback(self, msg):
