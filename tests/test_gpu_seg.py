@@ -128,3 +128,32 @@ def test_hipgraph_replay_is_identical(state, cuda_device):
     for img, ref in ((a, la), (b, lb), (a, la)):
         net.forward(img)
         assert torch.equal(net.logits, ref)
+
+
+def test_config_a_640x480_against_oracle(state, cuda_device):
+    """BASELINE configs[0] size: 640x480 frame (263 GFLOP) -- logits 19 x 116 x 156 as SURVEY 8a states."""
+    rel, agree = _compare(state, "f32", 480, 640, cuda_device, seed=3)
+    print("f32 480x640: max rel err %.3e, argmax agreement %.5f" % (rel, agree))
+    assert rel <= 1e-3 and agree >= 0.999
+    rel, agree = _compare(state, "bf16", 480, 640, cuda_device, seed=3)
+    print("bf16 480x640: max rel err %.3e, argmax agreement %.5f" % (rel, agree))
+    assert rel <= 6e-2 and agree >= 0.95
+
+
+def test_real_camera_size_1440x1920(state, cuda_device):
+    """The cameras deliver 1920x1440 (src/camera.py:114); the reference's video tool expects a 356 x 476 label map for
+    it (video_generator.py:126-127).  No oracle at this size (2.4 TFLOP on the CPU): shape, determinism, and agreement
+    between the bf16 and the fp32-input paths."""
+    import torch
+    from vision_semantic_segmentation_amd import SemanticSegmentation
+    img = np.random.default_rng(9).integers(0, 256, size=(1440, 1920, 3), dtype=np.uint8)
+    seg16 = SemanticSegmentation(_cfg("bf16"), device=cuda_device, state_dict=state)
+    a = seg16.segmentation(img)
+    assert a.shape == (356, 476) and a.dtype == np.int64
+    assert np.array_equal(a, seg16.segmentation(img))
+    seg32 = SemanticSegmentation(_cfg("f32"), device=cuda_device, state_dict=state)
+    l16, l32 = seg16.logits(img), seg32.logits(img)
+    rel = float((l16 - l32).abs().max() / l32.abs().max())
+    agree = float((l16.argmax(0) == l32.argmax(0)).float().mean())
+    print("1440x1920 bf16 vs f32 paths: max rel diff %.3e, argmax agreement %.5f" % (rel, agree))
+    assert rel <= 6e-2 and agree >= 0.95
