@@ -34,6 +34,7 @@ extern "C" {
 #define AVL_F32 0
 #define AVL_F64 1
 #define AVL_BF16 2
+#define AVL_F16 3
 
 /* vote-mask layout (one uint32 per grid cell, 0 between frames):
  *   bit i        (i < 16) : some point of map class i fell into the cell this frame
@@ -160,7 +161,7 @@ int avl_grid_box_filter(const void* src, void* dst, int map_dtype, int Hm, int W
  * the Python host folds BatchNorm into the convolutions, lays activations out as NHWC
  * ([H*W rows][channels], row stride `ld` elements, so channel slices of a wider buffer give
  * torch.cat for free) and hands the library a flat list of ops; avl_seg_plan_run() launches them in
- * order on one stream.  Activations are AVL_BF16 (bf16 MFMA, fp32 accumulate) or AVL_F32
+ * order on one stream.  Activations are AVL_BF16 / AVL_F16 (16x16x32 MFMA, fp32 accumulate) or AVL_F32
  * (fp32-input MFMA, the reference's precision).  Biases are always fp32.
  *
  * Every buffer named by an op must stay allocated while the plan lives; `*_rows` is the number of
@@ -180,7 +181,7 @@ int avl_grid_box_filter(const void* src, void* dst, int map_dtype, int Hm, int W
 
 typedef struct avl_seg_op {
     int32_t kind;            /* AVL_OP_*                                                        */
-    int32_t dtype;           /* activation type of in/in2/out: AVL_BF16 or AVL_F32              */
+    int32_t dtype;           /* activation type of in/in2/out: AVL_BF16, AVL_F16 or AVL_F32      */
     const void* in;          /* input activation (STEM: uint8 image; GEMV/GAP-out: fp32)       */
     const void* in2;         /* GEMM: residual added before the ReLU, or NULL; GAP: fp32 scratch [256][C];
                                 DWCONV: 32 zero bytes (what a tap outside the image reads)          */

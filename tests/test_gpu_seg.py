@@ -61,6 +61,15 @@ def test_bf16_logits_close_to_oracle(state, hw, cuda_device):
     assert agree >= 0.95
 
 
+@pytest.mark.parametrize("hw", [(96, 128), (320, 416)])
+def test_f16_logits_close_to_oracle(state, hw, cuda_device):
+    """MODEL.PRECISION = "f16": same MFMA rate as bf16, 3 more significand bits per activation."""
+    rel, agree = _compare(state, "f16", hw[0], hw[1], cuda_device)
+    print("f16 %dx%d: max rel err %.3e, argmax agreement %.5f" % (hw[0], hw[1], rel, agree))
+    assert rel <= 8e-3
+    assert agree >= 0.99
+
+
 def test_checkpoint_format_roundtrip(state, cuda_device, tmp_path):
     """The reference's file format: {'model': state_dict} with DataParallel's 'module.' prefix."""
     import torch

@@ -9,7 +9,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AVL_HIP_LIB", os.path.join(_HERE, "libavl_hip.so"))   # override for A/B kernel experiments
 
-AVL_F32, AVL_F64, AVL_BF16 = 0, 1, 2
+AVL_F32, AVL_F64, AVL_BF16, AVL_F16 = 0, 1, 2, 3
 AVL_SRC_RGB, AVL_SRC_CLASSMAP = 0, 1
 AVL_MAX_MAP_CLASSES = 16
 

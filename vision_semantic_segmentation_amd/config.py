@@ -94,7 +94,7 @@ def get_network_cfg_defaults():
     C.MODEL.DECODER.REFINE_CHANNELS = [256, 256]
     C.MODEL.DECODER.REFINE_KERNEL_SIZE = [3, 3]
     # build-specific (not in the reference): activation precision of the HIP conv stack
-    C.MODEL.PRECISION = "bf16"     # "bf16" (MFMA bf16, fp32 accumulate) or "f32" (fp32-input MFMA)
+    C.MODEL.PRECISION = "bf16"     # "bf16" | "f16" (16x16x32 MFMA, fp32 accumulate; f16 keeps 3 more mantissa bits) | "f32" (fp32-input MFMA)
     C.MODEL.SEED = 0               # seed of the random weights used when MODEL.WEIGHT == ""
     C.MODEL.HIP_GRAPH = True       # replay the ~90-kernel plan as one hipGraph launch per frame
     return C

@@ -439,7 +439,7 @@ int validate_conv_op(const avl_seg_op& op) {
             AVL_REQUIRE(op.weight && op.bias && op.out_c == 64 && op.in_c == 3, "stem expects 3 -> 64 channels");
             AVL_REQUIRE(op.out_h == (op.in_h + 6 - 7) / 2 + 1 && op.out_w == (op.in_w + 6 - 7) / 2 + 1, "stem output size");
             AVL_REQUIRE(op.out_rows >= out_pix && op.out_ld >= 64 && (op.out_ld * es) % 16 == 0, "stem output buffer");
-            AVL_REQUIRE(op.w_layout == 0 || (op.w_layout == 1 && op.dtype == AVL_BF16), "stem weight layout %d", op.w_layout);
+            AVL_REQUIRE(op.w_layout == 0 || (op.w_layout == 1 && is_half(op.dtype)), "stem weight layout %d", op.w_layout);
             return AVL_OK;
         case AVL_OP_GEMV:
             AVL_REQUIRE(op.weight && op.in_c > 0 && op.out_c > 0, "gemv shapes");
@@ -454,7 +454,7 @@ int validate_conv_op(const avl_seg_op& op) {
         default:
             break;
     }
-    AVL_REQUIRE(op.dtype == AVL_BF16 || op.dtype == AVL_F32, "op %d dtype %d", op.kind, op.dtype);
+    AVL_REQUIRE(is_half(op.dtype) || op.dtype == AVL_F32, "op %d dtype %d", op.kind, op.dtype);
     AVL_REQUIRE(op.in_c % 8 == 0 || (op.kind == AVL_OP_GCONV), "op %d: channels %d not a multiple of 8", op.kind, op.in_c);
     AVL_REQUIRE(op.in_rows >= in_pix && op.out_rows >= out_pix, "op %d: allocated rows too small", op.kind);
     AVL_REQUIRE(op.in_ld >= op.in_c && op.out_ld >= op.out_c, "op %d: leading dims", op.kind);
@@ -508,6 +508,7 @@ int launch_conv_op(const avl_seg_op& op, hipStream_t s) {
         return AVL_OK;
     }
     if (op.dtype == AVL_BF16) return launch_typed<bf16>(op, s);
+    if (op.dtype == AVL_F16) return launch_typed<f16>(op, s);
     return launch_typed<float>(op, s);
 }
 

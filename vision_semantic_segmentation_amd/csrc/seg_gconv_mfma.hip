@@ -20,18 +20,21 @@ namespace {
 constexpr int TW = 32;          // output tile width  (2 sub-tiles of 16 pixels)
 constexpr int CC = 64;          // channels per workgroup (2 windows of 32)
 
+template <typename HT>
 struct GconvArgs {
-    const bf16* in;
-    const bf16* w;       // [window][nj 2][tap 9][i 16][ci 32]
+    const HT* in;
+    const HT* w;          // [window][nj 2][tap 9][i 16][ci 32]
     const float* bias;   // [C]
-    bf16* out;
+    HT* out;
     int H, W, in_ld, OH, OW, out_ld, C;
     int stride, dil;
     int th;              // output tile height (8, or 4 for stride 2)
     int tiles_x, tiles_y, cchunks;
 };
 
-__global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs p) {
+template <typename HT>
+__global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs<HT> p) {
+    typedef typename Half16<HT>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,7 +63,7 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs p) {
             const int iy = iy0 + ly, ix = ix0 + lx;
             const bool inside = pix < npix && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-            const bf16* src = p.in + ((long long)cy * p.W + cx) * p.in_ld + c0 + ((cphys ^ (pix & 7)) << 3);
+            const HT* src = p.in + ((long long)cy * p.W + cx) * p.in_ld + c0 + ((cphys ^ (pix & 7)) << 3);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(lds + gi * 1024), 16, 0, 0);
             oob |= (inside ? 0u : 1u) << it;
@@ -77,14 +80,14 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs p) {
     const int win = wave & 1;                  // window inside the 64-channel chunk
     const int half = wave >> 1;                // which half of the tile's sub-tiles
     const int fr = lane & 15, kq = lane >> 4;
-    bf16x8 wf[2][9];
+    v8 wf[2][9];
     {
-        const bf16* wp = p.w + (long long)(cchunk * 2 + win) * (2 * 9 * 16 * 32);
+        const HT* wp = p.w + (long long)(cchunk * 2 + win) * (2 * 9 * 16 * 32);
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
             for (int t = 0; t < 9; ++t)
-                wf[nj][t] = *reinterpret_cast<const bf16x8*>(wp + ((nj * 9 + t) * 16 + fr) * 32 + kq * 8);
+                wf[nj][t] = *reinterpret_cast<const v8*>(wp + ((nj * 9 + t) * 16 + fr) * 32 + kq * 8);
     }
     // lane's 8 output channels: window base + q*8 + nj*4 + r
     const int cbase = c0 + win * 32 + kq * 8;
@@ -104,17 +107,17 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs p) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         // all nine tap fragments are requested before the first MFMA: the LDS latency is paid once per sub-tile,
         // not once per tap (the read -> 2 MFMA -> read chain left the matrix pipe idle ~2/3 of the time)
-        bf16x8 a[9];
+        v8 a[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int pix = (sy * s + (t / 3) * d) * in_tw + sx * s + (t % 3) * d;
-            a[t] = *reinterpret_cast<const bf16x8*>(lds + pix * 128 + ((chunk_in ^ (pix & 7)) << 4));
+            a[t] = *reinterpret_cast<const v8*>(lds + pix * 128 + ((chunk_in ^ (pix & 7)) << 4));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t], a[t], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][t], a[t], acc1, 0, 0, 0);
+            acc0 = Half16<HT>::mfma(wf[0][t], a[t], acc0);
+            acc1 = Half16<HT>::mfma(wf[1][t], a[t], acc1);
         }
         const int oy = oy0 + sy, ox = ox0 + sx;
         if (oy < p.OH && ox < p.OW) {
@@ -124,7 +127,7 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs p) {
                 v[r] = fmaxf(acc0[r] + bias[r], 0.f);
                 v[4 + r] = fmaxf(acc1[r] + bias[4 + r], 0.f);
             }
-            Vec8<bf16>::store(p.out + ((long long)oy * p.OW + ox) * p.out_ld + cbase, v);
+            Vec8<HT>::store(p.out + ((long long)oy * p.OW + ox) * p.out_ld + cbase, v);
         }
     }
 }
@@ -137,30 +140,35 @@ int gconv_mfma_lds_bytes(int stride, int dil, int& th) {
     return ((in_th * in_tw + 7) / 8) * 1024;      // whole 8-pixel DMA groups
 }
 
-int launch_gconv_mfma(const avl_seg_op& op, hipStream_t s) {
-    GconvArgs a;
-    a.in = static_cast<const bf16*>(op.in);
-    a.w = static_cast<const bf16*>(op.weight);
+template <typename HT>
+int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
+    GconvArgs<HT> a;
+    a.in = static_cast<const HT*>(op.in);
+    a.w = static_cast<const HT*>(op.weight);
     a.bias = op.bias;
-    a.out = static_cast<bf16*>(op.out);
+    a.out = static_cast<HT*>(op.out);
     a.H = op.in_h; a.W = op.in_w; a.in_ld = op.in_ld; a.OH = op.out_h; a.OW = op.out_w; a.out_ld = op.out_ld; a.C = op.in_c;
     a.stride = op.stride; a.dil = op.dil;
     const int ldsb = gconv_mfma_lds_bytes(op.stride, op.dil, a.th);
     a.tiles_x = (op.out_w + TW - 1) / TW;
     a.tiles_y = (op.out_h + a.th - 1) / a.th;
     a.cchunks = op.in_c / CC;
-    static int attr_bytes = 0;
-    if (ldsb > attr_bytes) {
-        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_bytes = 160 * 1024;
+    static bool attr = false;
+    if (!attr) {
+        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv_mfma<HT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
     }
-    hipLaunchKernelGGL(k_gconv_mfma, dim3(a.tiles_x * a.tiles_y * a.cchunks), dim3(256), ldsb, s, a);
+    hipLaunchKernelGGL(k_gconv_mfma<HT>, dim3(a.tiles_x * a.tiles_y * a.cchunks), dim3(256), ldsb, s, a);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
 
+int launch_gconv_mfma(const avl_seg_op& op, hipStream_t s) {
+    return op.dtype == AVL_F16 ? launch_gconv_typed<f16>(op, s) : launch_gconv_typed<bf16>(op, s);
+}
+
 int validate_gconv_mfma(const avl_seg_op& op) {
-    AVL_REQUIRE(op.dtype == AVL_BF16, "MFMA grouped conv is bf16 only");
+    AVL_REQUIRE(is_half(op.dtype), "MFMA grouped conv needs a 16-bit activation type");
     AVL_REQUIRE(op.in_c % CC == 0, "MFMA grouped conv needs channels %% 64 == 0 (got %d)", op.in_c);
     const int cg = op.in_c / op.groups;
     AVL_REQUIRE(cg <= 32 && 32 % cg == 0, "MFMA grouped conv needs <= 32 channels per group dividing 32 (got %d)", cg);

@@ -134,18 +134,18 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm(GemmArgs p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int chunk = kk * 4 + kq;
-                bf16x8 af[4], wf[4];
+                typedef typename Half16<T>::v8 v8;
+                v8 af[4], wf[4];
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
-                    af[mi] = *reinterpret_cast<const bf16x8*>(ab + a_row[mi] * 128 + ((chunk ^ (a_row[mi] & 7)) << 4));
+                    af[mi] = *reinterpret_cast<const v8*>(ab + a_row[mi] * 128 + ((chunk ^ (a_row[mi] & 7)) << 4));
 #pragma unroll
                 for (int nj = 0; nj < 4; ++nj)
-                    wf[nj] = *reinterpret_cast<const bf16x8*>(wb + w_row[nj] * 128 + ((chunk ^ (w_row[nj] & 7)) << 4));
+                    wf[nj] = *reinterpret_cast<const v8*>(wb + w_row[nj] * 128 + ((chunk ^ (w_row[nj] & 7)) << 4));
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                    for (int nj = 0; nj < 4; ++nj)
-                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nj], af[mi], acc[mi][nj], 0, 0, 0);
+                    for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<T>::mfma(wf[nj], af[mi], acc[mi][nj]);
             }
         } else {
             // fp32: lane kq owns k = 8*kq .. 8*kq+7 of the 32-wide step; MFMA step s sums k-set {s, 8+s, 16+s, 24+s}
@@ -235,8 +235,9 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm(GemmArgs p) {
 //     (a __syncthreads() would drain the LDS-DMA queue with vmcnt(0));
 //   * weight-tile swizzle key is built from the row bits the permuted fragment rows actually vary in
 //     (conflict-free ds_read_b128 for both operands).
-template <int WM, int WN, int MI, int STAGES, int PROBE = 0>
+template <typename H, int WM, int WN, int MI, int STAGES, int PROBE = 0>
 __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtiles) {
+    typedef typename Half16<H>::v8 v8;
     constexpr int NW = WM * WN, BM = WM * MI * 16, BN = WN * 64;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
     constexpr int A_INSTR = BM / 8 / NW, W_INSTR = BN / 8 / NW;
@@ -339,53 +340,53 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtile
             const bool feed = pt < total;                  // stage g+STAGES-1 -> the slot consumed in step g-1
             const char* base = lds + (g % STAGES) * BUF;
             if (PROBE == 1) { if (feed) issue(); continue; }      // DMA only
-            auto rd_w = [&](int kk, int nj) { return *reinterpret_cast<const bf16x8*>(base + w_off[nj] + (((kk * 4 + kq) ^ w_key[nj]) << 4)); };
-            auto rd_a = [&](int kk, int mi) { return *reinterpret_cast<const bf16x8*>(base + a_off[mi] + (((kk * 4 + kq) ^ a_key[mi]) << 4)); };
+            auto rd_w = [&](int kk, int nj) { return *reinterpret_cast<const v8*>(base + w_off[nj] + (((kk * 4 + kq) ^ w_key[nj]) << 4)); };
+            auto rd_a = [&](int kk, int mi) { return *reinterpret_cast<const v8*>(base + a_off[mi] + (((kk * 4 + kq) ^ a_key[mi]) << 4)); };
             // The step is cut into 4 MFMA groups; the next stage's DMA instructions and the second K-half's fragment
             // reads are placed BETWEEN the groups (a DMA burst issued in one go in front of the MFMAs was measured to
             // serialise with them: DMA-only 75 us + MFMA-only 65 us = 131 us for layer4.conv1).
-            constexpr int H = MI / 2;
+            constexpr int HALF = MI / 2;
             // Waves w and w + NW/2 share a SIMD.  The second half issues its DMA at the head of the step, the first
             // half in the middle, so that on every SIMD one wave is in an MFMA group while its partner pays the
             // (100+ cycle per instruction) LDS-DMA issue cost, instead of both doing the same thing at the same time.
             const bool early = MI == 8 && NW >= 8 && wave >= NW / 2;      // measured: +4-7 % on 256x256 tiles, -4 % on 256x128
             if (feed && early) { issue_part(0, 2); issue_part(1, 2); }
-            bf16x8 wa[4], wb[4], af[MI];
+            v8 wa[4], wb[4], af[MI];
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) wa[nj] = rd_w(0, nj);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) af[mi] = rd_a(0, mi);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mi = 0; mi < H; ++mi)
+            for (int mi = 0; mi < HALF; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nj], af[mi], acc[mi][nj], 0, 0, 0);
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<H>::mfma(wa[nj], af[mi], acc[mi][nj]);
             __builtin_amdgcn_sched_barrier(0);
             if (feed && !early) issue_part(0, 2);
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) wb[nj] = rd_w(1, nj);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mi = H; mi < MI; ++mi)
+            for (int mi = HALF; mi < MI; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nj], af[mi], acc[mi][nj], 0, 0, 0);
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<H>::mfma(wa[nj], af[mi], acc[mi][nj]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mi = 0; mi < H; ++mi) af[mi] = rd_a(1, mi);
+            for (int mi = 0; mi < HALF; ++mi) af[mi] = rd_a(1, mi);
             if (feed && !early) issue_part(1, 2);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mi = 0; mi < H; ++mi)
+            for (int mi = 0; mi < HALF; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nj], af[mi], acc[mi][nj], 0, 0, 0);
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<H>::mfma(wb[nj], af[mi], acc[mi][nj]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mi = H; mi < MI; ++mi) af[mi] = rd_a(1, mi);
+            for (int mi = HALF; mi < MI; ++mi) af[mi] = rd_a(1, mi);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mi = H; mi < MI; ++mi)
+            for (int mi = HALF; mi < MI; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[nj], af[mi], acc[mi][nj], 0, 0, 0);
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<H>::mfma(wb[nj], af[mi], acc[mi][nj]);
         }
         // ---- epilogue of tile t (the next tile's first stages are already in flight).  All residual loads
         // are issued before the first one is consumed, so their latency is paid once per tile, not per sub-tile.
@@ -394,15 +395,15 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtile
         constexpr int EB = 4;                       // sub-tiles per epilogue batch (residual registers: 8 per sub-tile)
 #pragma unroll
         for (int b0 = 0; b0 < MI; b0 += EB) {
-            bf16x8 res[EB][2];
+            v8 res[EB][2];
             if (p.R) {
 #pragma unroll
                 for (int e = 0; e < EB; ++e) {
                     const int m = mt * BM + wm * (MI * 16) + (b0 + e) * 16 + fr;
                     if (m < p.M && ncol_ok) {
-                        const bf16* rp = static_cast<const bf16*>(p.R) + (long long)m * p.ldr + nbase;
-                        res[e][0] = *reinterpret_cast<const bf16x8*>(rp);
-                        res[e][1] = *reinterpret_cast<const bf16x8*>(rp + 8);
+                        const H* rp = static_cast<const H*>(p.R) + (long long)m * p.ldr + nbase;
+                        res[e][0] = *reinterpret_cast<const v8*>(rp);
+                        res[e][1] = *reinterpret_cast<const v8*>(rp + 8);
                     }
                 }
             }
@@ -424,12 +425,12 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtile
 #pragma unroll
                         for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
                     }
-                    bf16* cp = static_cast<bf16*>(p.C) + (long long)m * p.ldc + nbase;
+                    H* cp = static_cast<H*>(p.C) + (long long)m * p.ldc + nbase;
                     float lo[8], hi[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { lo[i] = v[i]; hi[i] = v[8 + i]; }
-                    Vec8<bf16>::store(cp, lo);
-                    Vec8<bf16>::store(cp + 8, hi);
+                    Vec8<H>::store(cp, lo);
+                    Vec8<H>::store(cp + 8, hi);
                 }
             }
         }
@@ -437,13 +438,13 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtile
     }
 }
 
-template <int WM, int WN, int MI, int STAGES>
+template <typename H, int WM, int WN, int MI, int STAGES>
 int launch_ring(const GemmArgs& a0, int M, hipStream_t s) {
     constexpr int BM = WM * MI * 16, BN = WN * 64, LDS = STAGES * (BM + BN) * 128;
     static_assert(LDS <= 160 * 1024, "ring does not fit LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<WM, WN, MI, STAGES>),
+        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<H, WM, WN, MI, STAGES>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
@@ -454,13 +455,13 @@ int launch_ring(const GemmArgs& a0, int M, hipStream_t s) {
     const int grid = total < 256 ? total : 256;
     static const int probe = getenv("AVL_GEMM_PROBE") ? atoi(getenv("AVL_GEMM_PROBE")) : 0;   // timing experiments only
     if (probe == 1) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<WM, WN, MI, STAGES, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        hipLaunchKernelGGL((k_gemm_ring<WM, WN, MI, STAGES, 1>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<H, WM, WN, MI, STAGES, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipLaunchKernelGGL((k_gemm_ring<H, WM, WN, MI, STAGES, 1>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
     } else if (probe == 2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<WM, WN, MI, STAGES, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        hipLaunchKernelGGL((k_gemm_ring<WM, WN, MI, STAGES, 2>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<H, WM, WN, MI, STAGES, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipLaunchKernelGGL((k_gemm_ring<H, WM, WN, MI, STAGES, 2>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
     } else
-        hipLaunchKernelGGL((k_gemm_ring<WM, WN, MI, STAGES>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
+        hipLaunchKernelGGL((k_gemm_ring<H, WM, WN, MI, STAGES>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
@@ -489,7 +490,7 @@ inline TileCfg pick_tile(const avl_seg_op& op) {
 
 int validate_gemm(const avl_seg_op& op) {
     const int es = elem_size(op.dtype);
-    AVL_REQUIRE(op.dtype == AVL_BF16 || op.dtype == AVL_F32, "GEMM dtype %d", op.dtype);
+    AVL_REQUIRE(is_half(op.dtype) || op.dtype == AVL_F32, "GEMM dtype %d", op.dtype);
     AVL_REQUIRE(op.in && op.out && op.weight && op.bias, "GEMM has NULL buffers");
     const int M = op.out_h * op.out_w, K = op.in_c, N = op.out_c;
     AVL_REQUIRE(M > 0 && N > 0 && K > 0, "GEMM M/N/K = %d/%d/%d", M, N, K);
@@ -522,18 +523,23 @@ int launch_gemm(const avl_seg_op& op, hipStream_t s) {
     // bf16 variants.  w_layout: 0 = pick by shape, 1 = v1 (128x128, 2 LDS buffers, 2 workgroups/CU),
     // 2 = ring 256x128 x3 stages, 3 = ring 256x256 x2 stages, 4 = ring 256x128 (4 waves) x3 stages.
     // 256x256 halves the L2->LDS bytes per flop (the measured limiter) but needs >= ~200 tiles to fill 256 CUs.
-    if (op.dtype == AVL_BF16 && op.w_layout != 1 && t.bn == 128 && !op.out_f32 && a.N % 128 == 0 &&
+    if (is_half(op.dtype) && op.w_layout != 1 && t.bn == 128 && !op.out_f32 && a.N % 128 == 0 &&
         op.in_rows >= (a.M + 255) / 256 * 256) {
         const bool can256 = a.N % 256 == 0 && op.w_rows % 256 == 0;
         int v = op.w_layout;
         if (v == 0) v = (can256 && ((a.M + 255) / 256) * (a.N / 256) >= 192) ? 3 : 2;
-        if (v == 3 && can256) return launch_ring<2, 4, 8, 2>(a, a.M, s);
-        if (v == 4) return launch_ring<2, 2, 8, 3>(a, a.M, s);
-        return launch_ring<4, 2, 4, 3>(a, a.M, s);
+        const bool bf = op.dtype == AVL_BF16;
+        if (v == 3 && can256) return bf ? launch_ring<bf16, 2, 4, 8, 2>(a, a.M, s) : launch_ring<f16, 2, 4, 8, 2>(a, a.M, s);
+        if (v == 4) return bf ? launch_ring<bf16, 2, 2, 8, 3>(a, a.M, s) : launch_ring<f16, 2, 2, 8, 3>(a, a.M, s);
+        return bf ? launch_ring<bf16, 4, 2, 4, 3>(a, a.M, s) : launch_ring<f16, 4, 2, 4, 3>(a, a.M, s);
     }
     if (op.dtype == AVL_BF16) {
         if (t.bn == 64) return launch_cfg<bf16, 4, 1>(a, mtiles, s);
         return launch_cfg<bf16, 2, 2>(a, mtiles, s);
+    }
+    if (op.dtype == AVL_F16) {
+        if (t.bn == 64) return launch_cfg<f16, 4, 1>(a, mtiles, s);
+        return launch_cfg<f16, 2, 2>(a, mtiles, s);
     }
     if (t.bn == 64) return launch_cfg<float, 4, 1>(a, mtiles, s);
     return launch_cfg<float, 2, 2>(a, mtiles, s);

@@ -16,16 +16,19 @@ constexpr int S_TH = 8, S_TW = 32;
 constexpr int IN_TH = 2 * S_TH + 5, IN_TW = 2 * S_TW + 5;     // 21 x 69 input pixels
 constexpr int ROW = 224;                                      // bf16 values per LDS row (>= 69*3 + slack for the pad taps)
 
+template <typename HT>
 struct StemArgs {
     const unsigned char* img;
-    const bf16* w;        // [nj 4][step 6][i 16][k 32]
+    const HT* w;           // [nj 4][step 6][i 16][k 32]
     const float* bias;    // [64]
-    bf16* out;
+    HT* out;
     int H, W, OH, OW, out_ld, tiles_x;
 };
 
-__global__ void __launch_bounds__(256) k_stem_mfma(StemArgs p) {
-    __shared__ __attribute__((aligned(16))) bf16 tile[(IN_TH + 1) * ROW];
+template <typename HT>
+__global__ void __launch_bounds__(256) k_stem_mfma(StemArgs<HT> p) {
+    typedef typename Half16<HT>::v8 v8;
+    __shared__ __attribute__((aligned(16))) HT tile[(IN_TH + 1) * ROW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
@@ -39,15 +42,15 @@ __global__ void __launch_bounds__(256) k_stem_mfma(StemArgs p) {
         float v = 0.f;
         if (ly < IN_TH && lx < IN_TW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
             v = ((float)p.img[((long long)iy * p.W + ix) * 3 + ci] / 255.0f - mean[ci]) / stdv[ci];
-        tile[e] = (bf16)v;
+        tile[e] = (HT)v;
     }
     const int fr = lane & 15, kq = lane >> 4;
-    bf16x8 wf[4][6];
+    v8 wf[4][6];
 #pragma unroll
     for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
         for (int st = 0; st < 6; ++st)
-            wf[nj][st] = *reinterpret_cast<const bf16x8*>(p.w + ((nj * 6 + st) * 16 + fr) * 32 + kq * 8);
+            wf[nj][st] = *reinterpret_cast<const v8*>(p.w + ((nj * 6 + st) * 16 + fr) * 32 + kq * 8);
     float bias[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -66,17 +69,17 @@ __global__ void __launch_bounds__(256) k_stem_mfma(StemArgs p) {
             // chunk index q = st*4 + kq in [0,24): kernel row ky = q/3, 8-wide piece (q%3) of its 24 taps
             const int q = st * 4 + kq;
             const int ky = q / 3, piece = q - ky * 3;
-            bf16x8 a;
+            v8 a;
             if (q < 21) {
                 const uint32_t* src = reinterpret_cast<const uint32_t*>(tile + (sy * 2 + ky) * ROW + sx * 6 + piece * 8);
                 uint32_t u[4] = {src[0], src[1], src[2], src[3]};
                 __builtin_memcpy(&a, u, 16);
             } else {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) a[i] = (bf16)0.f;
+                for (int i = 0; i < 8; ++i) a[i] = (HT)0.f;
             }
 #pragma unroll
-            for (int nj = 0; nj < 4; ++nj) acc[nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nj][st], a, acc[nj], 0, 0, 0);
+            for (int nj = 0; nj < 4; ++nj) acc[nj] = Half16<HT>::mfma(wf[nj][st], a, acc[nj]);
         }
         const int oy = oy0 + sy, ox = ox0 + sx;
         if (oy < p.OH && ox < p.OW) {
@@ -88,27 +91,32 @@ __global__ void __launch_bounds__(256) k_stem_mfma(StemArgs p) {
                 hi[r] = fmaxf(acc[2][r] + bias[8 + r], 0.f);
                 hi[4 + r] = fmaxf(acc[3][r] + bias[12 + r], 0.f);
             }
-            bf16* op = p.out + ((long long)oy * p.OW + ox) * p.out_ld + kq * 16;
-            Vec8<bf16>::store(op, lo);
-            Vec8<bf16>::store(op + 8, hi);
+            HT* op = p.out + ((long long)oy * p.OW + ox) * p.out_ld + kq * 16;
+            Vec8<HT>::store(op, lo);
+            Vec8<HT>::store(op + 8, hi);
         }
     }
 }
 
 }  // namespace
 
-int launch_stem_mfma(const avl_seg_op& op, hipStream_t s) {
-    StemArgs a;
+template <typename HT>
+int launch_stem_typed(const avl_seg_op& op, hipStream_t s) {
+    StemArgs<HT> a;
     a.img = static_cast<const unsigned char*>(op.in);
-    a.w = static_cast<const bf16*>(op.weight);
+    a.w = static_cast<const HT*>(op.weight);
     a.bias = op.bias;
-    a.out = static_cast<bf16*>(op.out);
+    a.out = static_cast<HT*>(op.out);
     a.H = op.in_h; a.W = op.in_w; a.OH = op.out_h; a.OW = op.out_w; a.out_ld = op.out_ld;
     a.tiles_x = (op.out_w + S_TW - 1) / S_TW;
     const int tiles_y = (op.out_h + S_TH - 1) / S_TH;
-    hipLaunchKernelGGL(k_stem_mfma, dim3(a.tiles_x * tiles_y), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_stem_mfma<HT>, dim3(a.tiles_x * tiles_y), dim3(256), 0, s, a);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
+}
+
+int launch_stem_mfma(const avl_seg_op& op, hipStream_t s) {
+    return op.dtype == AVL_F16 ? launch_stem_typed<f16>(op, s) : launch_stem_typed<bf16>(op, s);
 }
 
 }  // namespace avl

@@ -8,6 +8,8 @@ namespace avl {
 
 typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
@@ -31,6 +33,35 @@ struct Vec8<bf16> {
 };
 
 template <>
+struct Vec8<f16> {
+    static __device__ __forceinline__ void load(const f16* p, float (&v)[8]) {
+        const f16x8 x = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)x[i];
+    }
+    static __device__ __forceinline__ void store(f16* p, const float (&v)[8]) {
+        f16x8 x;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = (f16)v[i];     // v_cvt_pk_f16_f32 / v_cvt_f16_f32: round to nearest even
+        *reinterpret_cast<f16x8*>(p) = x;
+    }
+};
+
+// the two 16-bit activation types: fragment vector type + the matching 16x16x32 MFMA (same rate for both)
+template <typename H>
+struct Half16;
+template <>
+struct Half16<bf16> {
+    typedef bf16x8 v8;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Half16<f16> {
+    typedef f16x8 v8;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+template <>
 struct Vec8<float> {
     static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
         const float4 a = *reinterpret_cast<const float4*>(p);
@@ -50,6 +81,7 @@ template <typename T>
 __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 
 inline int elem_size(int dtype) { return dtype == AVL_F32 ? 4 : 2; }
+inline bool is_half(int dtype) { return dtype == AVL_BF16 || dtype == AVL_F16; }
 
 // launchers implemented in seg_gemm.hip / seg_conv.hip; each validates its op and returns AVL_*
 int launch_gemm(const avl_seg_op& op, hipStream_t s);

@@ -210,12 +210,13 @@ class SegNet(object):
 
     def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8):
         assert output_stride == 8, "the reference configuration is OS8 (base_cfg.py:106)"
-        assert precision in ("bf16", "f32")
+        assert precision in ("bf16", "f16", "f32")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.H, self.W = int(height), int(width)
         self.precision = precision
-        self.act_dtype = torch.bfloat16 if precision == "bf16" else torch.float32
-        self.avl_dtype = _lib.AVL_BF16 if precision == "bf16" else _lib.AVL_F32
+        self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[precision]
+        self.avl_dtype = {"bf16": _lib.AVL_BF16, "f16": _lib.AVL_F16, "f32": _lib.AVL_F32}[precision]
+        self.half = precision != "f32"              # 16-bit activations: MFMA stem / grouped-conv kernels
         self.num_classes = num_classes
         self._keep = []            # every tensor the plan points at
         self._free = {}            # numel -> [tensor] pool of released activation buffers
@@ -312,8 +313,8 @@ class SegNet(object):
         # ---- stem: conv1 7x7 s2 + bn1 + relu (resnet.py:25-27), maxpool (:28)
         h2, w2 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         w, b = fold_bn(st, "backbone.conv1.weight", "backbone.bn1")
-        if self.precision == "bf16":
-            w_stem, stem_layout = self._dev(pack_stem_mfma(w), torch.bfloat16), 1
+        if self.half:
+            w_stem, stem_layout = self._dev(pack_stem_mfma(w), self.act_dtype), 1
         else:
             w_stem, stem_layout = self._dev(w.permute(2, 3, 1, 0).reshape(-1), torch.float32), 0   # [ky][kx][ci][co]
         b_stem = self._dev(b, torch.float32)
@@ -350,8 +351,8 @@ class SegNet(object):
                 # conv2 3x3 grouped + bn2 + relu
                 w, b = fold_bn(st, p + ".conv2.weight", p + ".bn2")
                 cg = width // GROUPS
-                if self.precision == "bf16" and width % 64 == 0 and 32 % cg == 0:
-                    wg_d, layout = self._dev(pack_gconv_windows(w, GROUPS), torch.bfloat16), 1
+                if self.half and width % 64 == 0 and 32 % cg == 0:
+                    wg_d, layout = self._dev(pack_gconv_windows(w, GROUPS), self.act_dtype), 1
                 else:
                     wg = w.reshape(GROUPS, cg, cg, 3, 3).permute(0, 3, 4, 2, 1).reshape(-1)   # [g][ky][kx][ci][co]
                     wg_d, layout = self._dev(wg, torch.float32), 0
