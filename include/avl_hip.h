@@ -135,6 +135,13 @@ int avl_colorize_labels(const uint8_t* labels, int lw, int lh, const uint8_t* pa
                         uint8_t* out, int out_w, int out_h, void* stream);
 
 
+/* ---- the node's image pre-processing (vision_semantic_segmentation_node.py:83-98) -----------
+ * cv2.cvtColor(BGR2RGB) -> cv2.undistort(K, dist) -> cv2.resize(INTER_AREA) by an integer factor, fused.
+ * bgr uint8[h][w][3]; K_host double[9] (row-major 3x3) and dist_host double[5] (k1,k2,p1,p2,k3), both NULL to
+ * skip the undistortion; rgb_out uint8[h/factor][w/factor][3]. */
+int avl_preprocess_image(const uint8_t* bgr, int h, int w, const double* K_host, const double* dist_host, int factor,
+                         uint8_t* rgb_out, void* stream);
+
 /* ---- the semantic point cloud mapping() publishes (src/mapping.py:316-317) ---------------
  * create_point_cloud (src/utils/utils_ros.py:31-59) without its per-point struct.pack loop: record k (16 bytes,
  * point_step 16) = float32 x,y,z of pcd[0:3][k] and uint32 rgba = r | g<<8 | b<<16 | 255<<24 of label[:,k].

@@ -103,7 +103,7 @@ def test_node_callback_and_fused_mapping(state, cuda_device):
     cfg.MAPPING.BOUNDARY = syn.centred_boundary(mo.PCD_ORIGIN_OFFSET[:2], 100.0)
     cfg.MAPPING.RESOLUTION = 0.5
     seg = SemanticSegmentation(cfg.VISION_SEM_SEG.SEM_SEG_NETWORK, device=cuda_device, state_dict=state)
-    node = VisionSemanticSegmentationNode(cfg, seg=seg)
+    node = VisionSemanticSegmentationNode(cfg, seg=seg, undistort=False)
     rng = np.random.default_rng(8)
     bgr = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
     colour = node.image_callback(Message(Header(frame_id="camera1"), data=bgr))
@@ -166,3 +166,29 @@ def test_real_camera_size_1440x1920(state, cuda_device):
     agree = float((l16.argmax(0) == l32.argmax(0)).float().mean())
     print("1440x1920 bf16 vs f32 paths: max rel diff %.3e, argmax agreement %.5f" % (rel, agree))
     assert rel <= 6e-2 and agree >= 0.95
+
+
+def test_preprocessing_matches_restatement(cuda_device):
+    """SURVEY 8f row 1 (vision_semantic_segmentation_node.py:83-98): BGR2RGB + cv2.undistort + INTER_AREA on the GPU vs the
+    NumPy restatement (OpenCV is absent: parity unpinned; both use float bilinear weights)."""
+    from oracle import preprocess_oracle as po
+    from vision_semantic_segmentation_amd.camera import camera_setup_1
+    from vision_semantic_segmentation_amd.vision_semantic_segmentation_node import preprocess_device
+    rng = np.random.default_rng(12)
+    cam = camera_setup_1()
+    coarse = rng.integers(0, 256, size=(45, 60, 3), dtype=np.uint8)
+    bgr = np.repeat(np.repeat(coarse, 32, axis=0), 32, axis=1)                  # 1440 x 1920 with structure
+    bgr = (bgr.astype(np.int32) + rng.integers(-8, 9, size=bgr.shape)).clip(0, 255).astype(np.uint8)
+    # channel swap only
+    assert np.array_equal(preprocess_device(bgr).cpu().numpy(), po.preprocess(bgr))
+    # swap + INTER_AREA 0.5 (the reference's example.yaml): integer path, exact
+    assert np.array_equal(preprocess_device(bgr, None, 2).cpu().numpy(), po.preprocess(bgr, factor=2))
+    assert np.array_equal(preprocess_device(bgr, None, 3).cpu().numpy(), po.preprocess(bgr, factor=3))
+    # + undistort: float bilinear on both sides; accumulation order may flip a rounding on isolated pixels
+    got = preprocess_device(bgr, cam, 1).cpu().numpy().astype(np.int32)
+    ref = po.preprocess(bgr, cam.K, cam.dist).astype(np.int32)
+    d = np.abs(got - ref)
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    got = preprocess_device(bgr, cam, 2).cpu().numpy().astype(np.int32)
+    ref = po.preprocess(bgr, cam.K, cam.dist, 2).astype(np.int32)
+    assert np.abs(got - ref).max() <= 1

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "avl_fused_frame": (_i, [C.POINTER(AvlGrid), _vp, _i, _i, _i64, _i64, _vp, _vp, _d, _i, _vp, _i, _i, _i, _i,
                              _vp, _vp, _vp, C.c_uint32, _vp]),
     "avl_colorize_labels": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "avl_preprocess_image": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "avl_pack_semantic_cloud": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "avl_render_bev_map": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "avl_render_bev_map_thresholds": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -159,3 +159,12 @@ extern "C" int avl_seg_plan_profile(avl_seg_plan* plan, void* stream, float* ms_
     }
     return AVL_OK;
 }
+
+namespace avl { int launch_preprocess(const unsigned char*, int, int, const double*, const double*, int, unsigned char*, hipStream_t); }
+extern "C" int avl_preprocess_image(const uint8_t* bgr, int h, int w, const double* K_host, const double* dist_host, int factor,
+                                    uint8_t* rgb_out, void* stream) {
+    AVL_REQUIRE(bgr && rgb_out && h > 0 && w > 0, "bad image buffers");
+    AVL_REQUIRE(factor >= 1 && h / factor > 0 && w / factor > 0, "downscale factor %d", factor);
+    AVL_REQUIRE((K_host == nullptr) == (dist_host == nullptr), "K_host and dist_host go together");
+    return avl::launch_preprocess(bgr, h, w, K_host, dist_host, factor, rgb_out, avl::as_stream(stream));
+}

@@ -68,14 +68,3 @@ class SemanticSegmentation(object):
         net = self.net_for(h, w)
         net.forward(image_in)
         return net.logits.permute(2, 0, 1)
-
-    @staticmethod
-    def resize_area(image, out_h, out_w):
-        """cv2.resize(..., INTER_AREA) slot of the node (vision_semantic_segmentation_node.py:92-98);
-        next row of SURVEY 8f.  Exact for integer scale factors (box mean), which is what IMAGE_SCALE = 0.5 gives."""
-        h, w = image.shape[:2]
-        if h % out_h == 0 and w % out_w == 0:
-            fy, fx = h // out_h, w // out_w
-            v = image.reshape(out_h, fy, out_w, fx, -1).astype(np.float32).mean(axis=(1, 3))
-            return np.clip(np.rint(v), 0, 255).astype(np.uint8)
-        raise NotImplementedError("INTER_AREA for non-integer scale factors is not built yet")

@@ -1,10 +1,10 @@
 """VisionSemanticSegmentationNode -- the reference's segmentation node
 (src/vision_semantic_segmentation_node.py:41-136) around the HIP segmentation stack.
 
-image_callback keeps the reference's sequence (:74-136): BGR->RGB, optional INTER_AREA downscale,
+image_callback keeps the reference's sequence (:74-136): BGR->RGB, cv2.undistort, optional INTER_AREA downscale,
 ``SemanticSegmentation.segmentation``, uint8 cast, INTER_NEAREST upscale to the input size, palette
-colouring, publish.  The upscale + colouring run as one HIP kernel (avl_colorize_labels); camera
-undistortion (:84-87, cv2.undistort) is listed as the next row of SURVEY section 8f and is a hook.
+colouring, publish.  Pre-processing is one HIP kernel (avl_preprocess_image), the upscale + colouring another
+(avl_colorize_labels); the frame is uploaded once and only the colour image comes back.
 """
 import ctypes as C
 
@@ -21,6 +21,25 @@ def _palette_host(labels):
     for k, lab in enumerate(labels[:256]):
         pal[k] = lab["color"]
     return (C.c_uint8 * 768)(*pal.ravel().tolist())
+
+
+def preprocess_device(bgr, camera=None, factor=1, stream=None):
+    """vision_semantic_segmentation_node.py:83-98 on the GPU (avl_preprocess_image): BGR->RGB, cv2.undistort with the
+    camera's K / dist (skipped when camera is None), INTER_AREA downscale by the integer `factor`.
+    bgr: uint8 [H,W,3] ndarray or CUDA tensor -> uint8 CUDA tensor [H/factor, W/factor, 3] (RGB)."""
+    t = bgr if isinstance(bgr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(bgr))
+    t = t.cuda().contiguous() if not t.is_cuda else t.contiguous()
+    assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3
+    h, w = int(t.shape[0]), int(t.shape[1])
+    out = torch.empty((h // factor, w // factor, 3), dtype=torch.uint8, device=t.device)
+    K = dist = None
+    if camera is not None:
+        K = (C.c_double * 9)(*np.asarray(camera.K, dtype=np.float64).ravel().tolist())
+        dist = (C.c_double * 5)(*np.asarray(camera.dist, dtype=np.float64).ravel()[:5].tolist())
+    s = torch.cuda.current_stream(t.device).cuda_stream if stream is None else stream
+    _lib.check(_lib.lib().avl_preprocess_image(C.c_void_p(t.data_ptr()), h, w, K, dist, int(factor), C.c_void_p(out.data_ptr()),
+                                               C.c_void_p(s)), "avl_preprocess_image")
+    return out
 
 
 def colorize_labels_device(labels_small, out_h, out_w, labels=None, stream=None):
@@ -42,7 +61,7 @@ def colorize_labels_device(labels_small, out_h, out_w, labels=None, stream=None)
 class VisionSemanticSegmentationNode(object):
     """Reference class: src/vision_semantic_segmentation_node.py:41."""
 
-    def __init__(self, cfg, seg=None, use_ros=False, publish=None, undistort=None):
+    def __init__(self, cfg, seg=None, use_ros=False, publish=None, undistort=True):
         if cfg.VISION_SEM_SEG.IMAGE_SCALE < 0 or cfg.VISION_SEM_SEG.IMAGE_SCALE > 1:
             raise ValueError("image scale should be in the range of [0, 1]")       # :43-44
         network_cfg = cfg.VISION_SEM_SEG.SEM_SEG_NETWORK
@@ -55,7 +74,7 @@ class VisionSemanticSegmentationNode(object):
         self.cam1 = camera_setup_1()
         self.image_scale = cfg.VISION_SEM_SEG.IMAGE_SCALE
         self.publish = publish          # callable(frame_id, colour image, header) or None
-        self.undistort = undistort      # callable(image, camera) or None (cv2.undistort slot, :84-87)
+        self.undistort = undistort      # the reference always undistorts camera1 / camera6 frames (:84-87)
         self.last_labels = None         # CUDA uint8 [h', w'] of the last frame (feeds the fused mapping path)
         if use_ros:
             self._setup_ros()
@@ -68,23 +87,26 @@ class VisionSemanticSegmentationNode(object):
         self.image_pub_cam1 = rospy.Publisher("/camera1/semantic", Image, queue_size=1)
         self.image_pub_cam6 = rospy.Publisher("/camera6/semantic", Image, queue_size=1)
 
+    def _downscale_factor(self):
+        """IMAGE_SCALE -> integer INTER_AREA factor (:92-98).  The reference's configs use 1.0 and 0.5."""
+        if self.image_scale >= 1:
+            return 1
+        f = int(round(1.0 / self.image_scale))
+        if abs(f * self.image_scale - 1.0) > 1e-9:
+            raise NotImplementedError("IMAGE_SCALE must be 1/integer for the GPU INTER_AREA path (got %r)" % self.image_scale)
+        return f
+
     def image_callback(self, msg):
-        """:74-136.  msg.data: uint8[H,W,3] BGR (as the camera driver publishes it).  Returns the
-        colourised uint8[H,W,3] image (also handed to ``publish``)."""
-        image_in = msg.data if isinstance(msg.data, np.ndarray) else np.asarray(msg.data)
-        image_in = image_in[:, :, ::-1]                                            # :83 BGR2RGB
-        cam = {"camera1": self.cam1, "camera6": self.cam6}.get(msg.header.frame_id)
-        if self.undistort is not None and cam is not None:
-            image_in = self.undistort(image_in, cam)                               # :84-87
-        h, w = image_in.shape[0], image_in.shape[1]
-        if self.image_scale < 1:                                                   # :92-98
-            rw, rh = int(w * self.image_scale), int(h * self.image_scale)
-            image_in_resized = self.seg.resize_area(image_in, rh, rw)
-        else:
-            image_in_resized = image_in
-        labels = self.seg.segmentation_device(np.ascontiguousarray(image_in_resized))   # :101-102 (uint8 on the GPU)
+        """:74-136.  msg.data: uint8[H,W,3] BGR (as the camera driver publishes it).  The whole chain runs on the GPU:
+        pre-processing (:83-98), segmentation (:101-102), nearest upscale + palette (:109-116); only the published
+        colour image comes back to the host.  Returns that uint8[H,W,3] image (also handed to ``publish``)."""
+        bgr = msg.data if isinstance(msg.data, (np.ndarray, torch.Tensor)) else np.asarray(msg.data)
+        h, w = int(bgr.shape[0]), int(bgr.shape[1])
+        cam = {"camera1": self.cam1, "camera6": self.cam6}.get(msg.header.frame_id)   # unknown frame ids: no undistortion (:88-89)
+        rgb_small = preprocess_device(bgr, cam if self.undistort else None, self._downscale_factor())
+        labels = self.seg.segmentation_device(rgb_small)
         self.last_labels = labels
-        colored = colorize_labels_device(labels, h, w, self.seg_color_ref)         # :109-116
+        colored = colorize_labels_device(labels, h, w, self.seg_color_ref)
         out = colored.cpu().numpy()
         if self.publish is not None:
             self.publish(msg.header.frame_id, out, msg.header)                     # :129-134
