@@ -140,31 +140,31 @@ __global__ void __launch_bounds__(kThreads) k_gconv(const T* __restrict__ in, in
 // core/nn/modules/conv.py:131-134 (groups = in_channels) + folded BN + ReLU.
 // weight: float [9][C]; one lane = one output pixel x 8 channels.
 // Work decomposition is by "comb": for dilation d the outputs with (y mod d, x mod d) = (ry, rx) only ever read
-// inputs of that same residue class (pad == d in ASPP), so one workgroup that owns a whole comb -- all channels of
-// it -- touches every input pixel it needs exactly once and shares nothing with any other workgroup: no halo is
-// re-fetched by another XCD (PMC showed 3-4.6x read amplification for the pixel-major order, whose vertical
-// neighbours land on different XCDs / L2s).  256 lanes = channel chunks of 8 (fastest, so a pixel's channels are
-// one contiguous read) x column lanes; a lane keeps its 9 x 8 weights in registers and walks its band of the comb
-// grid.  Dilation 1 (decoder, pad 0) is a single comb, cut into row/column bands instead.
+// inputs of that same residue class (pad == d in ASPP), so a workgroup that owns a comb shares no input with any
+// other workgroup: no halo is re-fetched by another XCD (PMC showed 3-4.6x read amplification for the pixel-major
+// order, whose vertical neighbours land on different XCDs / L2s).  256 lanes = up to 64 channel chunks of 8 (fastest:
+// 1 KB of a pixel is one contiguous read; wider groups push the rows a workgroup re-reads out of L2) x column lanes.
+// A lane keeps its 9 x 8 weights in registers, walks DOWN its grid column with a rolling 3-row window (3 loads per
+// output, two rows prefetched ahead) and chains small combs until it has ~32 outputs per weight load.
+// Dilation 1 (decoder) is a single comb, cut into bands of 16 rows x 2 columns per lane.
+// Measured at 1080p (5 layers): 0.44 ms pixel-per-lane with 9 loads -> 0.335 ms.
 struct DwGeom {
     int H, W, C, in_ld, OH, OW, out_ld, pad, dil, relu;
     int gh, gw;            // comb-grid size: outputs per residue class
     int band_h, band_w;    // grid rows / columns per workgroup
     int nby, nbx;          // bands per comb
-    int nchunk, cl;        // channel-chunk lanes and column lanes per workgroup
+    int nchunk, cl;        // channel-chunk lanes and pixel lanes per workgroup
     int cgroups;           // workgroups along channels (C / 8 / nchunk)
+    int units, upb;        // (comb, band) units in total / per workgroup
 };
 
 template <typename T>
 __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, const float* __restrict__ w,
                                                     const float* __restrict__ bias, T* __restrict__ out, const T* __restrict__ zero,
                                                     DwGeom g) {
-    int b = blockIdx.x;
-    const int cgrp = b % g.cgroups; b /= g.cgroups;
-    const int bx = b % g.nbx; b /= g.nbx;
-    const int by = b % g.nby; b /= g.nby;
-    const int rx = b % g.dil, ry = b / g.dil;
+    const int cgrp = blockIdx.x % g.cgroups, ub = blockIdx.x / g.cgroups;
     const int chunk = threadIdx.x % g.nchunk, cl = threadIdx.x / g.nchunk;
+    if (cl >= g.cl) return;
     const int c8 = cgrp * g.nchunk + chunk;
     float wt[9][8];
 #pragma unroll
@@ -180,48 +180,103 @@ __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, c
         const float4 b1 = *reinterpret_cast<const float4*>(bias + c8 * 8 + 4);
         bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
     }
-    const int gy1 = min((by + 1) * g.band_h, g.gh), gx1 = min((bx + 1) * g.band_w, g.gw);
     constexpr int NR = sizeof(T) == 2 ? 1 : 2;
-    for (int gy = by * g.band_h; gy < gy1; ++gy) {
-        const int oy = ry + gy * g.dil;
-        if (oy >= g.OH) break;
-        for (int gx = bx * g.band_w + cl; gx < gx1; gx += g.cl) {
-            const int ox = rx + gx * g.dil;
+    // 16-bit types: taps are paired (0,1)(2,3)(4,5)(6,7)(8,-) and each channel's two taps go through one
+    // v_dot2c_f32_{bf16,f16} (exact products, fp32 accumulate) -- 1 vector op per MAC instead of convert + FMA.
+    // The folded weights are rounded to the activation type for it, like every GEMM weight of the network.
+    uint32_t wp[5][8];
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const T lo = (T)wt[2 * pr][i], hi = (T)(pr < 4 ? wt[2 * pr + 1][i] : 0.f);
+                wp[pr][i] = (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
+            }
+    }
+    const int u_end = min(g.units, (ub + 1) * g.upb);
+    for (int u = ub * g.upb; u < u_end; ++u) {
+        int b = u;
+        const int bx = b % g.nbx; b /= g.nbx;
+        const int by = b % g.nby; b /= g.nby;
+        const int rx = b % g.dil, ry = b / g.dil;
+        const int gy0 = by * g.band_h, gx0 = bx * g.band_w;
+        const int bw = min(g.band_w, g.gw - gx0), bh = min(g.band_h, g.gh - gy0);
+        // A lane walks DOWN one grid column with a rolling window: the three taps of the next input row are fetched
+        // two outputs ahead of the one being computed, so an output costs 3 loads instead of 9 (the kernel is bound by
+        // L1/L2 request bandwidth, not by VALU or HBM).  A tap outside the image reads a zero page (pointer select).
+        for (int col = cl; col < bw; col += g.cl) {
+            const int ox = rx + (gx0 + col) * g.dil;
             if (ox >= g.OW) break;
-            // all nine taps are fetched before any is used: nine loads in flight.  A tap outside the image reads a
-            // zero page instead (pointer select), so no per-element masking; tap addresses are the centre address
-            // plus nine wave-uniform offsets.  (The kernel was VALU-bound: ~270 vector ops per 16-byte output.)
-            uint4 raw[9][NR];
-            const T* centre = in + ((long long)(oy - g.pad + g.dil) * g.W + (ox - g.pad + g.dil)) * g.in_ld + c8 * 8;
-            bool rok[3], cok[3];
+            bool cok[3];
+            long long coff[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const int iy = oy - g.pad + k * g.dil, ix = ox - g.pad + k * g.dil;
-                rok[k] = iy >= 0 && iy < g.H;
+                const int ix = ox - g.pad + k * g.dil;
                 cok[k] = ix >= 0 && ix < g.W;
+                coff[k] = (long long)ix * g.in_ld + c8 * 8;
             }
+            uint4 raw[9][NR], nxt[3][NR], nx2[3][NR];
+            auto load_row = [&](int iy, uint4 (*dst)[NR]) {
+                const bool rok = iy >= 0 && iy < g.H;
+                const T* rowp = in + (long long)iy * g.W * g.in_ld;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const long long off = ((long long)(t / 3 - 1) * g.dil * g.W + (t % 3 - 1) * g.dil) * g.in_ld;   // wave-uniform
-                const uint4* src = reinterpret_cast<const uint4*>((rok[t / 3] && cok[t % 3]) ? centre + off : zero);
-                raw[t][0] = src[0];
-                if constexpr (NR == 2) raw[t][1] = src[1];
-            }
+                for (int k = 0; k < 3; ++k) {
+                    const uint4* src = reinterpret_cast<const uint4*>((rok && cok[k]) ? rowp + coff[k] : zero);
+                    dst[k][0] = src[0];
+                    if constexpr (NR == 2) dst[k][1] = src[1];
+                }
+            };
+            const int oy0 = ry + gy0 * g.dil;
+            load_row(oy0 - g.pad, &raw[3]);
+            load_row(oy0 - g.pad + g.dil, &raw[6]);
+            load_row(oy0 - g.pad + 2 * g.dil, nxt);
+            if (bh > 1) load_row(oy0 - g.pad + 3 * g.dil, nx2);
+            for (int r = 0; r < bh; ++r) {
+                const int oy = oy0 + r * g.dil;
+                if (oy >= g.OH) break;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) {
+                        raw[k][q] = raw[3 + k][q];
+                        raw[3 + k][q] = raw[6 + k][q];
+                        raw[6 + k][q] = nxt[k][q];
+                        nxt[k][q] = nx2[k][q];
+                    }
+                if (r + 2 < bh) load_row(oy - g.pad + 4 * g.dil, nx2);
             float acc[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = bs[i];
+            if constexpr (sizeof(T) == 2) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                float v[8];
-                Vec8<T>::load(reinterpret_cast<const T*>(&raw[t][0]), v);
+                for (int pr = 0; pr < 5; ++pr) {
+                    const uint32_t* ra = reinterpret_cast<const uint32_t*>(&raw[2 * pr][0]);
+                    const uint32_t* rb = reinterpret_cast<const uint32_t*>(&raw[pr < 4 ? 2 * pr + 1 : 8][0]);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = fmaf(v[i], wt[t][i], acc[i]);
+                    for (int j = 0; j < 4; ++j) {
+                        // [tap a ch 2j | tap b ch 2j] and [tap a ch 2j+1 | tap b ch 2j+1]
+                        const uint32_t lo = pr < 4 ? __builtin_amdgcn_perm(rb[j], ra[j], 0x05040100u) : (ra[j] & 0xffffu);
+                        const uint32_t hi = pr < 4 ? __builtin_amdgcn_perm(rb[j], ra[j], 0x07060302u) : (ra[j] >> 16);
+                        acc[2 * j] = Half16<T>::dot2(lo, wp[pr][2 * j], acc[2 * j]);
+                        acc[2 * j + 1] = Half16<T>::dot2(hi, wp[pr][2 * j + 1], acc[2 * j + 1]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    float v[8];
+                    Vec8<T>::load(reinterpret_cast<const T*>(&raw[t][0]), v);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(v[i], wt[t][i], acc[i]);
+                }
             }
             if (g.relu) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[i] = fmaxf(acc[i], 0.f);
             }
             Vec8<T>::store(out + ((long long)oy * g.OW + ox) * g.out_ld + c8 * 8, acc);
+            }
         }
     }
 }
@@ -447,20 +502,30 @@ int launch_typed(const avl_seg_op& op, hipStream_t s) {
             g.gh = (op.out_h + op.dil - 1) / op.dil;
             g.gw = (op.out_w + op.dil - 1) / op.dil;
             const int chunks = op.in_c / 8;
-            g.nchunk = chunks < kThreads ? chunks : kThreads;
-            while (kThreads % g.nchunk) --g.nchunk;                      // lanes = nchunk x cl exactly
-            while (chunks % g.nchunk) --g.nchunk;
+            // channel lanes: at most 64 chunks (1 KB of a pixel) per workgroup, so that the rows a workgroup re-reads
+            // two grid rows later (2 x gw x 512 B) are still in its XCD's L2 with ~1000 workgroups in flight
+            static const int max_chunk = [] { const char* e = getenv("AVL_DW_NCHUNK"); return e ? atoi(e) : 64; }();
+            g.nchunk = chunks < max_chunk ? chunks : max_chunk;
+            while (chunks % g.nchunk) --g.nchunk;      // lanes beyond nchunk x cl idle (C = 304: 19 x 13 of 256)
             g.cl = kThreads / g.nchunk;
             g.cgroups = chunks / g.nchunk;
-            // bands: keep >= ~512 workgroups in flight, at most ~64 outputs per lane
-            g.band_w = g.gw;
-            if (g.cl > 1) { g.band_w = 8 * g.cl; if (g.band_w > g.gw) g.band_w = g.gw; }
-            g.band_h = g.gh;
-            const long long combs = (long long)op.dil * op.dil * g.cgroups;
+            const long long combs = (long long)op.dil * op.dil;
+            g.band_w = g.gw; g.band_h = g.gh;
+            if (op.dil == 1) {
+                // a single comb: bands of 2 columns per lane x 16 rows (2 halo rows re-read per band)
+                g.band_w = 2 * g.cl < g.gw ? 2 * g.cl : g.gw;
+                g.band_h = g.gh < 16 ? g.gh : 16;
+                const int nbx = (g.gw + g.band_w - 1) / g.band_w;
+                while (g.band_h > 4 && (long long)g.cgroups * nbx * ((g.gh + g.band_h - 1) / g.band_h) < 512) g.band_h = (g.band_h + 1) / 2;
+            }
             g.nbx = (g.gw + g.band_w - 1) / g.band_w;
-            while (g.band_h > 4 && combs * g.nbx * ((g.gh + g.band_h - 1) / g.band_h) < 512) g.band_h = (g.band_h + 1) / 2;
             g.nby = (g.gh + g.band_h - 1) / g.band_h;
-            hipLaunchKernelGGL(k_dwconv<T>, dim3((unsigned)(combs * g.nby * g.nbx)), dim3(kThreads), 0, s, in, w, op.bias, out,
+            g.units = (int)(combs * g.nby * g.nbx);
+            // ~32 outputs per lane amortise the 18 weight loads: small combs are chained in one workgroup
+            const int target = 32 * g.cl, unit_px = g.band_h * g.band_w;
+            g.upb = (op.dil == 1 || unit_px >= target) ? 1 : (target + unit_px - 1) / unit_px;
+            const unsigned nblk = (unsigned)((g.units + g.upb - 1) / g.upb) * g.cgroups;
+            hipLaunchKernelGGL(k_dwconv<T>, dim3(nblk), dim3(kThreads), 0, s, in, w, op.bias, out,
                                static_cast<const T*>(op.in2), g);
             break;
         }

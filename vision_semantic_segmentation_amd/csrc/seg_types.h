@@ -54,11 +54,20 @@ template <>
 struct Half16<bf16> {
     typedef bf16x8 v8;
     static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    // c + a.lo*b.lo + a.hi*b.hi on packed pairs (v_dot2c_f32_bf16)
+    static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+        typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
+    }
 };
 template <>
 struct Half16<f16> {
     typedef f16x8 v8;
     static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+        typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
+    }
 };
 
 template <>
