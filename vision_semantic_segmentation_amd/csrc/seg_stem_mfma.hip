@@ -29,20 +29,40 @@ template <typename HT>
 __global__ void __launch_bounds__(256) k_stem_mfma(StemArgs<HT> p) {
     typedef typename Half16<HT>::v8 v8;
     __shared__ __attribute__((aligned(16))) HT tile[(IN_TH + 1) * ROW];
+    __shared__ HT lut[3 * 256];        // normalised value of every (channel, byte): exact divisions, done once
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
     const int oy0 = ty * S_TH, ox0 = tx * S_TW;
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
-    for (int e = tid; e < (IN_TH + 1) * ROW; e += 256) {
+    // all of a lane's byte loads are issued before the first conversion (the element-at-a-time loop was a chain of
+    // ~20 dependent global-load latencies per workgroup and cost more than the MFMAs)
+    constexpr int NE = ((IN_TH + 1) * ROW + 255) / 256;
+    unsigned char px[NE];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + i * 256;
         const int ly = e / ROW, lc = e - ly * ROW;
-        const int lx = lc / 3, ci = lc - lx * 3;
+        const int lx = lc / 3;
         const int iy = iy0 + ly, ix = ix0 + lx;
-        float v = 0.f;
-        if (ly < IN_TH && lx < IN_TW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-            v = ((float)p.img[((long long)iy * p.W + ix) * 3 + ci] / 255.0f - mean[ci]) / stdv[ci];
-        tile[e] = (HT)v;
+        const bool ok = ly < IN_TH && lx < IN_TW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);      // unconditional load, masked below
+        px[i] = p.img[((long long)cy * p.W + cx) * 3 + (lc - lx * 3)];
+        okmask |= (ok ? 1u : 0u) << i;
+    }
+    // while the loads are in flight: the 768-entry table
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) lut[ci * 256 + tid] = (HT)(((float)tid / 255.0f - mean[ci]) / stdv[ci]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + i * 256;
+        if (e < (IN_TH + 1) * ROW) {
+            const int ci = (e % ROW) % 3;
+            tile[e] = ((okmask >> i) & 1u) ? lut[ci * 256 + px[i]] : (HT)0.f;
+        }
     }
     const int fr = lane & 15, kq = lane >> 4;
     v8 wf[4][6];
