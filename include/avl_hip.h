@@ -160,6 +160,16 @@ int avl_render_bev_map_thresholds(const void* map, int map_dtype, int Hm, int Wm
                                   const int32_t* priority_host, const double* thresholds_host, uint8_t* out, void* stream);
 /* apply_filter (renderer.py:175-189): 3x3 mean, kernel float32(1/9), BORDER_REFLECT_101; dst != src */
 int avl_grid_box_filter(const void* src, void* dst, int map_dtype, int Hm, int Wm, int C, void* stream);
+/* End-of-run evaluation (test/test_semantic_mapping.py, called at src/mapping.py:341-344): convert_labels (:6-19) and the
+ * counting part of Test.iou (:127-161) in one pass over the rendered colour map.
+ *   color_map uint8[H][W][3]; mask uint8[>=H][mask_ld] (0 = invalid) or NULL;
+ *   labels_out uint8[H][W] or NULL: 1 road (128,64,128), 2 crosswalk (140,140,200), 3 lane (255,255,255),
+ *                                   4 sidewalk (244,35,232), 5 vegetation (107,142,35), 0 anything else / masked;
+ *   gt uint8[>=H][gt_ld] or NULL: ground-truth labels (pointer already at the shift_w/shift_h origin of :125-126);
+ *   counts uint64[64] (device): counts[g * 8 + l] = pixels with ground truth g (values > 7 counted as 7) and label l.
+ * IoU(c) = counts[c][c] / (sum_l counts[c][l] + sum_g counts[g][c] - counts[c][c]) etc. are formed on the host. */
+int avl_eval_map(const uint8_t* color_map, int H, int W, const uint8_t* mask, int mask_ld, const uint8_t* gt, int gt_ld,
+                 uint8_t* labels_out, unsigned long long* counts, void* stream);
 
 /* ---- a1-a5: segmentation forward (DeepLabV3+ / ResNeXt-50 OS8, eval mode) -------------------
  *

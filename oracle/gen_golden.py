@@ -14,6 +14,8 @@ What is imported from the reference:
   * src/camera.py   -> camera_setup_1 / camera_setup_6 (real import, numpy only).
   * src/network/core/nn/modules + deeplab_v3_plus/models/{aspp,decoder}.py -> real torch modules,
     CPU forward at small sizes with seeded weights and randomised BN statistics.
+  * test/test_semantic_mapping.py -> convert_labels (:6-19) and Test.iou (:127-161), compiled from their own
+    line ranges (the module as a whole is a SyntaxError) -- `python oracle/gen_golden.py eval`.
 The backbone (torchvision) cannot be imported here; it has no fixture (parity unpinned).
 
 The fixtures hold inputs and expected outputs only -- no reference source text.
@@ -259,8 +261,53 @@ def gen_render():
     print("render", a.shape, int((a.sum(axis=2) > 0).sum()), int((b.sum(axis=2) > 0).sum()))
 
 
+def gen_eval():
+    """test/test_semantic_mapping.py: convert_labels (:6-19) and Test.iou (:127-161).  The module does not compile as a
+    whole (a second `else:` in Test.__init__), so the two functions are compiled from their own line ranges of the
+    reference file -- read at generation time, nothing of it is kept -- and run on seeded maps."""
+    import contextlib
+    import io
+    import textwrap
+    lines = open(os.path.join(REF, "test", "test_semantic_mapping.py")).read().split("\n")
+    ns = {"np": np}
+    exec(compile("\n".join(lines[5:19]), "ref:convert_labels", "exec"), ns)              # def convert_labels
+    exec(compile(textwrap.dedent("\n".join(lines[126:161])), "ref:iou", "exec"), ns)     # def iou(self, ...)
+    assert "convert_labels" in ns and "iou" in ns
+    self_ = types.SimpleNamespace(class_lists=[1, 2, 3], d={0: "road", 1: "crosswalk", 2: "lane"})
+    rng = np.random.default_rng(21)
+    colours = np.array([[128, 64, 128], [140, 140, 200], [255, 255, 255], [244, 35, 232], [107, 142, 35]], dtype=np.uint8)
+    out = {}
+    for tag, (h, w) in (("a", (97, 131)), ("b", (240, 333))):
+        # a rendered map: palette colours, black, and a few near-miss colours (one channel off) that must stay 0
+        pick = rng.integers(0, 8, size=(h // 8 + 1, w // 8 + 1)).repeat(8, 0).repeat(8, 1)[:h, :w]
+        cmap = np.zeros((h, w, 3), dtype=np.uint8)
+        for k in range(5):
+            cmap[pick == k] = colours[k]
+        near = rng.random((h, w)) < 0.02
+        cmap[near] = np.array([128, 64, 129], dtype=np.uint8)
+        cmap[rng.random((h, w)) < 0.01] = np.array([140, 140, 201], dtype=np.uint8)
+        mask = (rng.random((h + 5, w + 7)) < 0.9).astype(np.float64)
+        truth = rng.integers(0, 4, size=((h + 20) // 8 + 1, (w + 30) // 8 + 1)).repeat(8, 0).repeat(8, 1)[:h + 20, :w + 30].astype(np.float64)
+        lab_nomask = ns["convert_labels"](cmap)
+        lab_mask = ns["convert_labels"](cmap, mask)
+        out[tag + "_cmap"], out[tag + "_mask"], out[tag + "_truth"] = cmap, mask, truth
+        out[tag + "_labels"], out[tag + "_labels_masked"] = lab_nomask, lab_mask
+        for sname, (sw, sh) in (("s0", (0, 0)), ("s1", (11, 23))):
+            gm = truth[sw:h + sw, sh:w + sh]
+            with contextlib.redirect_stdout(io.StringIO()):
+                iou_lists, miss = ns["iou"](self_, gm, lab_mask, verbose=False)
+            out["%s_%s_iou" % (tag, sname)] = np.array(iou_lists, dtype=np.float64)
+            out["%s_%s_miss" % (tag, sname)] = np.float64(miss)
+            out["%s_%s_shift" % (tag, sname)] = np.array([sw, sh], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "eval.npz"), **out)
+    print("wrote eval.npz (%d arrays)" % len(out))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "eval":
+        gen_eval()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "render":
         gen_render()
         sys.exit(0)
@@ -268,3 +315,4 @@ if __name__ == "__main__":
     gen_mapping(ref_mapping, ref_camera)
     gen_network()
     gen_render()
+    gen_eval()

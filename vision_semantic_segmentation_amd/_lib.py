@@ -47,6 +47,7 @@ _SIGNATURES = {
     "avl_render_bev_map": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "avl_render_bev_map_thresholds": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "avl_grid_box_filter": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "avl_eval_map": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
 }
 
 

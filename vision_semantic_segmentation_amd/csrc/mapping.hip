@@ -744,6 +744,56 @@ extern "C" int avl_render_bev_map_thresholds(const void* map, int map_dtype, int
     return AVL_OK;
 }
 
+// ---- end-of-run evaluation (test/test_semantic_mapping.py: convert_labels :6-19, Test.iou :127-161) -----------------
+// One pass over the rendered colour map: label = 1..5 for the five map colours (exact three-channel match, 0 otherwise
+// or where the validity mask is 0), and -- if a ground-truth map is given -- the joint histogram counts[gt][label]
+// (8 x 8 bins; gt bin 7 = "positive, but none of 1..6") from which IoU, accuracy and missing rate are integer sums.
+namespace {
+__global__ void __launch_bounds__(kBlock) k_eval_map(const uint8_t* __restrict__ color, int H, int W, const uint8_t* __restrict__ mask,
+                                                   int mask_ld, const uint8_t* __restrict__ gt, int gt_ld, uint8_t* __restrict__ labels,
+                                                   unsigned long long* __restrict__ counts) {
+    __shared__ unsigned int hist[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long long n = (long long)H * W;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+        const uint8_t r = color[i * 3], g = color[i * 3 + 1], b = color[i * 3 + 2];
+        int lab = 0;
+        if (r == 128 && g == 64 && b == 128) lab = 1;            // road
+        else if (r == 140 && g == 140 && b == 200) lab = 2;      // crosswalk
+        else if (r == 255 && g == 255 && b == 255) lab = 3;      // lane
+        else if (r == 244 && g == 35 && b == 232) lab = 4;       // sidewalk
+        else if (r == 107 && g == 142 && b == 35) lab = 5;       // vegetation
+        if (mask && mask[(long long)y * mask_ld + x] == 0) lab = 0;
+        if (labels) labels[i] = (uint8_t)lab;
+        if (gt) {
+            int gv = gt[(long long)y * gt_ld + x];
+            gv = gv > 7 ? 7 : gv;
+            atomicAdd(&hist[gv * 8 + lab], 1u);
+        }
+    }
+    __syncthreads();
+    if (gt && threadIdx.x < 64 && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+}  // namespace
+
+extern "C" int avl_eval_map(const uint8_t* color_map, int H, int W, const uint8_t* mask, int mask_ld, const uint8_t* gt, int gt_ld,
+                            uint8_t* labels_out, unsigned long long* counts, void* stream) {
+    AVL_REQUIRE(color_map && H > 0 && W > 0, "bad colour map");
+    AVL_REQUIRE(labels_out || gt, "avl_eval_map: nothing to compute (labels_out and gt are both NULL)");
+    AVL_REQUIRE(!mask || mask_ld >= W, "mask row stride %d < W %d", mask_ld, W);
+    AVL_REQUIRE(!gt || (gt_ld >= W && counts), "ground truth needs gt_ld >= W and a counts[64] buffer");
+    hipStream_t s = avl::as_stream(stream);
+    if (gt) AVL_HIP_CHECK(hipMemsetAsync(counts, 0, 64 * sizeof(unsigned long long), s));
+    const long long n = (long long)H * W;
+    long long blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 2048) blocks = 2048;                      // grid-stride: one LDS histogram flush per workgroup
+    hipLaunchKernelGGL(k_eval_map, dim3((unsigned)blocks), dim3(kBlock), 0, s, color_map, H, W, mask, mask_ld, gt, gt_ld, labels_out, counts);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
 extern "C" int avl_grid_box_filter(const void* src, void* dst, int map_dtype, int Hm, int Wm, int C, void* stream) {
     AVL_REQUIRE(src && dst && src != dst, "box filter needs distinct src and dst");
     AVL_REQUIRE(Hm > 1 && Wm > 1 && C > 0, "grid %dx%dx%d", Hm, Wm, C);

@@ -333,6 +333,37 @@ class SemanticMapping(object):
                                     "semantic_image": np.array(_to_numpy(semantic_image)), "pose": pose})
         img = self._as_device_u8(semantic_image)
         self.frame_device(self.pcd, self.pcd_frame_id, img, pose, camera_calibration, src_kind="rgb")
+        if self.save_map_to_file:                                                # mapping.py:323-345
+            self.save_map_to_file = False
+            self.finish_run()
+
+    def finish_run(self, output_dir=None):
+        """The shutdown branch of mapping() (mapping.py:323-345): dump the recorded inputs, smooth the grid
+        (apply_filter), render it (render_bev_map), write global_map.png and -- with GROUND_TRUTH_DIR set --
+        print IoU / accuracy / missing rate.  Filter, renderer and evaluation are GPU kernels; only the PNG and
+        the printed numbers leave the device.  Returns the colour map (uint8 [Hm,Wm,3] NumPy)."""
+        from .evaluation import Test
+        from .renderer import apply_filter, render_bev_map
+        if self.record_inputs and self.input_list:
+            self.save_inputs()
+        output_dir = output_dir or self.output_dir
+        os.makedirs(output_dir, exist_ok=True)
+        smooth = apply_filter(self.map_dev)                                      # :332, the filtered grid replaces the map
+        self.map_dev.copy_(smooth.to(self.map_dev.dtype))
+        self._map_host = None
+        color_dev = render_bev_map(self.map_dev, self.label_colors)              # :334
+        color_map = color_dev.cpu().numpy()
+        output_file = osp.join(output_dir, "global_map.png")
+        try:
+            from PIL import Image
+            # cv2.imwrite (:340) stores channel 0 of the array as BLUE; write the same file
+            Image.fromarray(np.ascontiguousarray(color_map[:, :, ::-1])).save(output_file)
+            self.logger.log("Saving image to %s" % output_file)
+        except ImportError:
+            np.save(output_file[:-4] + ".npy", color_map)
+        if self.ground_truth_dir != "":                                          # :342-345
+            Test(ground_truth_dir=self.ground_truth_dir, logger=self.logger).test_single_map(color_dev)
+        return color_map
 
     def frame_device(self, pcd, pcd_frame_id, semantic, pose, camera_calibration, src_kind="rgb",
                      image_size=None, net_palette=PALETTE_19, stream=None):
