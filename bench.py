@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -115,7 +115,7 @@ def main():
         gemm = [p for p in prof if p["kind"] == "gemm"]
         g_ms, g_fl = sum(p["ms"] for p in gemm), sum(p["flops"] for p in gemm)
         seg_ms, seg_fl = sum(p["ms"] for p in prof), sum(p["flops"] for p in prof)
-        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_F32_TFLOPS if args.precision == "f32" else PEAK_BF16_TFLOPS      # f16 and bf16 MFMA share one dense peak
         achieved = g_fl / g_ms / 1e9
         traffic, traffic_note = pmc_traffic(len(gemm))
         roofline = {"bound": "mfma", "kernel": "k_gemm_ring / k_gemm (1x1 conv, %d launches/frame)" % len(gemm), "achieved": round(achieved, 1),
