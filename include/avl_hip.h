@@ -195,6 +195,12 @@ int avl_eval_map(const uint8_t* color_map, int H, int W, const uint8_t* mask, in
 #define AVL_OP_GEMV 8        /* out[n] = act(sum_k w[n][k] in[k] + bias[n]) on fp32 vectors (pooled branch)      */
 #define AVL_OP_ARGMAX 9      /* torch.argmax(dim=1) over fp32 logits [M][C] -> uint8 (semantic_segmentation.py:56) */
 #define AVL_OP_SUBSAMPLE 10  /* rows of a stride-s 1x1 conv's input (Bottleneck.downsample in layer2.0)          */
+#define AVL_OP_DWPW 11       /* DepthwiseSeparableConv2d in ONE kernel (conv.py:103-141; the dilated ASPP branches):
+                                depthwise 3x3 (dil d, pad d) +bias+ReLU -> 1x1 conv +bias+ReLU, 16-bit types only.
+                                weight/bias = the 1x1 conv's (as AVL_OP_GEMM); in2 = depthwise parameters packed
+                                [K/64][8][6][8] dwords: five tap pairs (taps 2p | 2p+1 << 16 in the activation type)
+                                and the fp32 bias of each 8-channel chunk; then int32[ceil(H*W/128)]: the order in
+                                which the 128-pixel tiles are visited (a permutation; tiles a dilation apart adjacent) */
 
 typedef struct avl_seg_op {
     int32_t kind;            /* AVL_OP_*                                                        */

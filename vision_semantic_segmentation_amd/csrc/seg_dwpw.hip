@@ -1,0 +1,298 @@
+// Fused depthwise-separable block (core/nn/modules/conv.py:103-141, the three dilated ASPP branches aspp.py:45-63):
+//
+//   out[m][n] = relu( b2[n] + sum_k W2[n][k] * a[m][k] ),   a[m][k] = T( relu( b1[k] + sum_t w1[t][k] * x[pix(m) + off_t][k] ) )
+//
+// Unfused, the depthwise result a (M x 2048, 132 MB at 1080p) is written to HBM and read back by the 1x1 GEMM, and
+// both kernels are bound by exactly that traffic (75 + 44 us per branch).  Here a workgroup owns 128 pixels x all
+// 256 output channels; for every 64-channel K-step its 512 lanes compute the 128 x 64 slice of `a` on the vector ALUs
+// (9 taps, 16 outputs per lane, the same paired v_dot2c order as k_dwconv, so `a` is bit-identical to the unfused one),
+// write it into LDS in the swizzled layout the MFMA fragments are read from, and multiply it with the weight slice
+// that LDS-DMA brought in meanwhile.  `a` never exists in HBM.
+//   * taps: buffer_load_dwordx4 with a range-checked descriptor -- a tap outside the image gets an out-of-range
+//     offset and the hardware returns zeros (no pointer select, no zero page); the K-step advances the scalar offset;
+//   * depthwise weights/bias of all K-steps sit in LDS for the whole tile (K/64 x 1.5 KB <= 48 KB);
+//   * while the MFMAs of step s run, the taps of step s+1 are in flight and its `a` slice is computed: the kernel is
+//     VALU/L1-bound (~2k cycles per step per SIMD), the matrix work hides under it.
+#include "seg_types.h"
+
+namespace avl {
+namespace {
+
+constexpr int TM = 128;              // pixels per workgroup
+constexpr int TN = 256;              // output channels per workgroup
+constexpr int A_STAGE = TM * 128;    // 16 KB: 128 rows x 64 k x 2 B
+constexpr int W_STAGE = TN * 128;    // 32 KB
+constexpr int LDS_W = 0, LDS_A = 2 * W_STAGE, LDS_P = LDS_A + 2 * A_STAGE;   // params after the two rings
+constexpr int P_STEP = 8 * 6 * 8 * 4;                                         // bytes of depthwise parameters per K-step
+
+struct DwPwArgs {
+    const void* X;
+    const void* W;
+    const float* bias;
+    const uint32_t* dwp;     // [K/64][chunk 8][6][8] dwords: 5 tap pairs (lo = tap 2p, hi = tap 2p+1, 16-bit type) + fp32 bias
+    const int* order;        // [mtiles] pixel-tile visited by the i-th workgroup slot (see launch_dwpw), behind the parameters
+    int mtiles, per_xcd;
+    void* C;
+    int H, Wd, ldx, ldc, M, N, K, dil, ntiles;
+    unsigned x_bytes;
+};
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <typename HT>
+__global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
+    typedef typename Half16<HT>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    // Workgroups b, b+8, ... share an XCD and run at the same time; slot (xcd, i) takes the (xcd * per_xcd + i)-th tile
+    // of an order in which tiles whose rows are a multiple of the dilation apart are neighbours: such tiles read the
+    // same input rows (as top / centre / bottom taps), and only tiles that are in flight on the SAME L2 at the same
+    // K-step can share them -- otherwise every input row comes in from HBM three times.
+    const int nt = blockIdx.x % p.ntiles;
+    const int bm = blockIdx.x / p.ntiles, slot = (bm & 7) * p.per_xcd + (bm >> 3);
+    if (slot >= p.mtiles) return;
+    const int mt = p.order[slot];
+    const int nk = p.K / 64;
+    const unsigned lds_base = lds_addr(lds);
+
+    // ---- depthwise parameters of every K-step -> LDS
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.dwp);
+        uint4* dst = reinterpret_cast<uint4*>(lds + LDS_P);
+        for (int i = tid; i < nk * (P_STEP / 16); i += 512) dst[i] = src[i];
+    }
+
+    // ---- producer geometry: lane -> 8-channel chunk of two pixels (rows r0, r0 + 64 of the tile)
+    const int chunk = tid & 7, r0 = tid >> 3;
+    unsigned voff[2][9];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int m = mt * TM + r0 + q * 64;
+        const int y = m / p.Wd, x = m - y * p.Wd;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = y + (t / 3 - 1) * p.dil, ix = x + (t % 3 - 1) * p.dil;
+            const bool ok = m < p.M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd;
+            voff[q][t] = ok ? (unsigned)(((long long)iy * p.Wd + ix) * p.ldx + chunk * 8) * 2u : 0x7fffff00u;   // >= x_bytes: reads as 0
+        }
+    }
+    // raw buffer descriptor {base, stride 0, num_records = bytes, 32-bit data format}: out-of-range offsets load zeros
+    v4i xres;
+    {
+        const unsigned long long xa = reinterpret_cast<unsigned long long>(p.X);
+        xres[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xa);
+        xres[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xa >> 32) & 0xffff);
+        xres[2] = __builtin_amdgcn_readfirstlane((int)p.x_bytes);
+        xres[3] = 0x00020000;
+    }
+
+    // ---- weight DMA sources (as in k_gemm_ring): lane -> (row of an 8-row group, physical 16-byte chunk)
+    const int srow = lane >> 3, schunk = lane & 7;
+    const char* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (i * 8 + wave) * 8 + srow;
+        const int key = ((r >> 1) & 1) | (((r >> 4) & 3) << 1);
+        w_src[i] = static_cast<const char*>(p.W) + (long long)(nt * TN + r) * p.K * 2 + ((schunk ^ key) << 4);
+    }
+    auto issue_w = [&](int s) {
+        const unsigned base = lds_base + LDS_W + (s & 1) * W_STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_asm(w_src[i] + (long long)s * 128, base + i * 8 * 1024);
+    };
+
+    // ---- consumer geometry (64 x 64 per wave, product transposed: a lane ends with 16 consecutive channels of a pixel)
+    const int fr = lane & 15, kq = lane >> 4;
+    int a_off[4], w_off[4], a_key[4], w_key[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int row = wm * 64 + mi * 16 + fr;
+        a_off[mi] = LDS_A + row * 128;
+        a_key[mi] = row & 7;
+    }
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) {
+        const int row = wn * 64 + (fr >> 2) * 16 + nj * 4 + (fr & 3);
+        w_off[nj] = LDS_W + row * 128;
+        w_key[nj] = ((row >> 1) & 1) | (((row >> 4) & 3) << 1);
+    }
+    f32x4 acc[4][4];
+    {
+        const int nb = nt * TN + wn * 64 + kq * 16;
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + nb + 4 * nj);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[mi][nj] = f32x4{b.x, b.y, b.z, b.w};
+        }
+    }
+
+    v4i raw[2][9];
+    // The tap loads are issued from inline asm and waited for by hand (taps_ready): loads that stay in flight across
+    // the loop back-edge make hipcc fall back to vmcnt(0) in front of every use, which would expose their latency.
+    auto load_taps = [&](int s, int q) {
+        const int soff = __builtin_amdgcn_readfirstlane(s * 128);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(raw[q][t]) : "v"(voff[q][t]), "s"(xres), "s"(soff) : "memory");
+    };
+    // N = vector-memory operations issued after the taps of pixel q (they complete in issue order)
+    auto taps_ready = [&](int q, int younger) {
+#define AVL_TAPS_WAIT(N)                                                                                                         \
+    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                        \
+                 : "+v"(raw[q][0]), "+v"(raw[q][1]), "+v"(raw[q][2]), "+v"(raw[q][3]), "+v"(raw[q][4]), "+v"(raw[q][5]),          \
+                   "+v"(raw[q][6]), "+v"(raw[q][7]), "+v"(raw[q][8])                                                              \
+                 :: "memory")
+        if (younger >= 13) AVL_TAPS_WAIT(13);
+        else if (younger >= 9) AVL_TAPS_WAIT(9);
+        else if (younger >= 4) AVL_TAPS_WAIT(4);
+        else AVL_TAPS_WAIT(0);
+#undef AVL_TAPS_WAIT
+    };
+    // depthwise 3x3 of K-step s for pixel q of this lane -> A ring slot s & 1 (tap pairs exactly as k_dwconv)
+    auto produce_a = [&](int s, int q) {
+        const uint32_t* pp = reinterpret_cast<const uint32_t*>(lds + LDS_P + s * P_STEP + chunk * (6 * 8 * 4));
+        float o[8];
+        {
+            const float4 b0 = *reinterpret_cast<const float4*>(pp + 5 * 8), b1 = *reinterpret_cast<const float4*>(pp + 5 * 8 + 4);
+            o[0] = b0.x; o[1] = b0.y; o[2] = b0.z; o[3] = b0.w;
+            o[4] = b1.x; o[5] = b1.y; o[6] = b1.z; o[7] = b1.w;
+        }
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const uint4 w0 = *reinterpret_cast<const uint4*>(pp + pr * 8), w1 = *reinterpret_cast<const uint4*>(pp + pr * 8 + 4);
+            const uint32_t wp[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            const v4i ra = raw[q][2 * pr], rb = raw[q][pr < 4 ? 2 * pr + 1 : 8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t ua = (uint32_t)ra[j], ub = (uint32_t)rb[j];
+                const uint32_t lo = pr < 4 ? __builtin_amdgcn_perm(ub, ua, 0x05040100u) : (ua & 0xffffu);
+                const uint32_t hi = pr < 4 ? __builtin_amdgcn_perm(ub, ua, 0x07060302u) : (ua >> 16);
+                o[2 * j] = Half16<HT>::dot2(lo, wp[2 * j], o[2 * j]);
+                o[2 * j + 1] = Half16<HT>::dot2(hi, wp[2 * j + 1], o[2 * j + 1]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = fmaxf(o[i], 0.f);
+        const int row = r0 + q * 64;
+        HT* dst = reinterpret_cast<HT*>(lds + LDS_A + (s & 1) * A_STAGE + row * 128 + ((chunk ^ (row & 7)) << 4));
+        Vec8<HT>::store(dst, o);
+    };
+
+    // ---- prologue: A(0), W(0); the taps of step 1 are requested AFTER the W(0) DMA (the counted waits rely on it)
+    load_taps(0, 0);
+    load_taps(0, 1);
+    __syncthreads();                 // parameters are in LDS
+    taps_ready(0, 0);
+    taps_ready(1, 0);
+    produce_a(0, 0);
+    produce_a(0, 1);
+    issue_w(0);
+    if (nk > 1) { load_taps(1, 0); load_taps(1, 1); }
+
+    // Step s: the MFMAs of slice s, the depthwise slice s+1 (its taps were requested a whole step ago) and, as each
+    // pixel's tap registers free up, the requests for slice s+2.  vmcnt counts in issue order:
+    //   top of step s : younger than the W(s) DMA are the 18 taps of slice s+1        -> vmcnt(18) = "W(s) landed"
+    //   pixel 0 of s+1: younger are pixel 1's 9 taps and the 4 DMA of W(s+1)          -> vmcnt(13)
+    //   pixel 1 of s+1: younger are the 4 DMA and pixel 0's 9 taps of slice s+2 (if any) -> vmcnt(13) / vmcnt(4)
+    // (one half of the depthwise work between the two MFMA groups measured 10 % faster than all of it after them)
+    for (int s = 0; s < nk; ++s) {
+        const bool more = s + 1 < nk, more2 = s + 2 < nk;
+        if (more) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (more) issue_w(s + 1);
+        const char* base = lds;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            v8 wa[4], af[4];
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj)
+                wa[nj] = *reinterpret_cast<const v8*>(base + (s & 1) * W_STAGE + w_off[nj] + (((kk * 4 + kq) ^ w_key[nj]) << 4));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                af[mi] = *reinterpret_cast<const v8*>(base + (s & 1) * A_STAGE + a_off[mi] + (((kk * 4 + kq) ^ a_key[mi]) << 4));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<HT>::mfma(wa[nj], af[mi], acc[mi][nj]);
+            if (more) {
+                taps_ready(kk, kk == 0 ? 13 : (more2 ? 13 : 4));
+                produce_a(s + 1, kk);
+                if (more2) load_taps(s + 2, kk);
+            }
+        }
+    }
+
+    // ---- epilogue: ReLU, convert, store (bias was the accumulators' start value)
+    const int nbase = nt * TN + wn * 64 + kq * 16;
+    if (nbase + 16 <= p.N) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = mt * TM + wm * 64 + mi * 16 + fr;
+            if (m < p.M) {
+                float lo[8], hi[8];
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        lo[nj * 4 + r] = fmaxf(acc[mi][nj][r], 0.f);
+                        hi[nj * 4 + r] = fmaxf(acc[mi][2 + nj][r], 0.f);
+                    }
+                HT* cp = static_cast<HT*>(p.C) + (long long)m * p.ldc + nbase;
+                Vec8<HT>::store(cp, lo);
+                Vec8<HT>::store(cp + 8, hi);
+            }
+        }
+    }
+}
+
+template <typename HT>
+int launch_dwpw_typed(const DwPwArgs& a, int mtiles, hipStream_t s) {
+    const int lds_bytes = LDS_P + (a.K / 64) * P_STEP;
+    static bool attr = false;
+    if (!attr) {
+        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw<HT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_dwpw<HT>, dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+}  // namespace
+
+int validate_dwpw(const avl_seg_op& op) {
+    AVL_REQUIRE(is_half(op.dtype), "fused depthwise+pointwise needs a 16-bit activation type");
+    AVL_REQUIRE(op.in && op.out && op.weight && op.bias && op.in2, "dwpw has NULL buffers");
+    const int M = op.out_h * op.out_w, K = op.in_c, N = op.out_c;
+    AVL_REQUIRE(op.in_h == op.out_h && op.in_w == op.out_w && op.stride == 1 && op.ksize == 3 && op.dil >= 1 && op.pad == op.dil,
+                "dwpw geometry: 3x3, stride 1, pad == dilation (same-size output)");
+    AVL_REQUIRE(K % 64 == 0 && K <= 2048, "dwpw K = %d (multiple of 64, <= 2048: the depthwise parameters live in LDS)", K);
+    AVL_REQUIRE(N % 16 == 0 && op.w_rows >= (N + TN - 1) / TN * TN, "dwpw N = %d / weight rows %d", N, op.w_rows);
+    AVL_REQUIRE(op.in_ld >= K && (op.in_ld * 2) % 16 == 0, "dwpw in_ld %d", op.in_ld);
+    AVL_REQUIRE(op.out_ld >= N && (op.out_ld * 2) % 16 == 0, "dwpw out_ld %d", op.out_ld);
+    AVL_REQUIRE(op.in_rows >= M && op.out_rows >= M, "dwpw rows");
+    AVL_REQUIRE((long long)op.in_rows * op.in_ld * 2 < 0x7fffff00LL, "dwpw input larger than a buffer descriptor's range");
+    AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.in) | reinterpret_cast<uintptr_t>(op.weight) | reinterpret_cast<uintptr_t>(op.out) |
+                 reinterpret_cast<uintptr_t>(op.bias) | reinterpret_cast<uintptr_t>(op.in2)) % 16 == 0, "dwpw buffers must be 16-byte aligned");
+    return AVL_OK;
+}
+
+int launch_dwpw(const avl_seg_op& op, hipStream_t s) {
+    DwPwArgs a;
+    a.X = op.in; a.W = op.weight; a.bias = op.bias; a.dwp = static_cast<const uint32_t*>(op.in2); a.C = op.out;
+    a.H = op.in_h; a.Wd = op.in_w; a.ldx = op.in_ld; a.ldc = op.out_ld;
+    a.M = op.out_h * op.out_w; a.N = op.out_c; a.K = op.in_c; a.dil = op.dil;
+    a.ntiles = (a.N + TN - 1) / TN;
+    a.x_bytes = (unsigned)((long long)op.in_rows * op.in_ld * 2);
+    const int mtiles = (a.M + TM - 1) / TM;
+    a.mtiles = mtiles;
+    a.per_xcd = (mtiles + 7) / 8;
+    a.order = reinterpret_cast<const int*>(a.dwp + (a.K / 64) * (P_STEP / 4));
+    return op.dtype == AVL_F16 ? launch_dwpw_typed<f16>(a, mtiles, s) : launch_dwpw_typed<bf16>(a, mtiles, s);
+}
+
+}  // namespace avl

@@ -42,26 +42,6 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// The same DMA issued from inline asm: hipcc then does not know LDS is being written behind its back, so it
-// neither drains the queue (vmcnt(0)) in front of every ds_read nor before the next DMA; completion is
-// counted by hand (s_waitcnt vmcnt(N) + s_barrier in the caller).  M0 carries the wave-uniform LDS base.
-__device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(g), "s"(lds_byte_addr)
-        : "memory");
-}
-
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
-}
-
 template <typename T, int WM, int WN>
 __global__ void __launch_bounds__(WM* WN * 64) k_gemm(GemmArgs p) {
     constexpr int NW = WM * WN, BM = WM * 64, BN = WN * 64;

@@ -16,6 +16,7 @@ namespace {
 int validate(const avl_seg_op& op, int index) {
     int rc;
     if (op.kind == AVL_OP_GEMM) rc = validate_gemm(op);
+    else if (op.kind == AVL_OP_DWPW) rc = validate_dwpw(op);
     else rc = validate_conv_op(op);
     if (rc != AVL_OK) {
         char msg[400];
@@ -27,6 +28,7 @@ int validate(const avl_seg_op& op, int index) {
 
 int launch(const avl_seg_op& op, hipStream_t s) {
     if (op.kind == AVL_OP_GEMM) return launch_gemm(op, s);
+    if (op.kind == AVL_OP_DWPW) return launch_dwpw(op, s);
     return launch_conv_op(op, s);
 }
 
@@ -51,6 +53,10 @@ void work(const avl_seg_op& op, double& flops, double& bytes) {
             break;
         case AVL_OP_DWCONV:
             flops = 2.0 * out_pix * op.out_c * 9;
+            break;
+        case AVL_OP_DWPW:
+            flops = 2.0 * out_pix * op.in_c * 9 + 2.0 * out_pix * op.out_c * op.in_c;
+            bytes += (double)op.out_c * op.in_c * es;
             break;
         case AVL_OP_BILINEAR:
             flops = 8.0 * out_pix * op.out_c;

@@ -89,6 +89,26 @@ __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 template <typename T>
 __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 
+// The same DMA issued from inline asm: hipcc then does not know LDS is being written behind its back, so it
+// neither drains the queue (vmcnt(0)) in front of every ds_read nor before the next DMA; completion is
+// counted by hand (s_waitcnt vmcnt(N) + s_barrier in the caller).  M0 carries the wave-uniform LDS base.
+__device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(lds_byte_addr)
+        : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+
 inline int elem_size(int dtype) { return dtype == AVL_F32 ? 4 : 2; }
 inline bool is_half(int dtype) { return dtype == AVL_BF16 || dtype == AVL_F16; }
 
@@ -100,5 +120,7 @@ int validate_conv_op(const avl_seg_op& op);
 int launch_gconv_mfma(const avl_seg_op& op, hipStream_t s);
 int validate_gconv_mfma(const avl_seg_op& op);
 int launch_stem_mfma(const avl_seg_op& op, hipStream_t s);
+int launch_dwpw(const avl_seg_op& op, hipStream_t s);
+int validate_dwpw(const avl_seg_op& op);
 
 }  // namespace avl

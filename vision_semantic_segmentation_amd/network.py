@@ -27,8 +27,8 @@ from . import _lib
 
 BN_EPS = 1e-5
 
-OP_STEM, OP_MAXPOOL, OP_GEMM, OP_GCONV, OP_DWCONV, OP_BILINEAR, OP_GAP, OP_GEMV, OP_ARGMAX, OP_SUBSAMPLE = range(1, 11)
-OP_NAMES = {1: "stem", 2: "maxpool", 3: "gemm", 4: "gconv", 5: "dwconv", 6: "bilinear", 7: "gap", 8: "gemv", 9: "argmax", 10: "subsample"}
+OP_STEM, OP_MAXPOOL, OP_GEMM, OP_GCONV, OP_DWCONV, OP_BILINEAR, OP_GAP, OP_GEMV, OP_ARGMAX, OP_SUBSAMPLE, OP_DWPW = range(1, 12)
+OP_NAMES = {1: "stem", 2: "maxpool", 3: "gemm", 4: "gconv", 5: "dwconv", 6: "bilinear", 7: "gap", 8: "gemv", 9: "argmax", 10: "subsample", 11: "dwpw"}
 
 
 class AvlSegOp(C.Structure):
@@ -198,6 +198,35 @@ def pack_gconv_windows(w, groups):
     return out.reshape(-1)
 
 
+def pack_dw_pairs(w, b, act_dtype):
+    """Depthwise parameters for the fused depthwise+pointwise kernel (AVL_OP_DWPW): w float64 [C][1][3][3] and b [C]
+    (BN folded) -> int32 [C/64][chunk 8][6][8]: five tap pairs per channel (tap 2p in the low half, tap 2p+1 in the
+    high half, rounded fp32 -> activation type exactly as k_dwconv does in-kernel; the ninth tap pairs with zero) and
+    the fp32 bias bits."""
+    c = w.shape[0]
+    assert c % 64 == 0
+    w9 = w.reshape(c, 9).to(torch.float32)                      # the unfused kernel receives fp32 and rounds from there
+    w16 = torch.cat([w9, torch.zeros((c, 1), dtype=torch.float32)], dim=1).to(act_dtype)          # [C][10]
+    bits = w16.view(torch.int16).to(torch.int32) & 0xFFFF                                          # raw 16-bit patterns
+    pairs = bits[:, 0::2] | (bits[:, 1::2] << 16)                                                   # [C][5]
+    bias_bits = b.to(torch.float32).view(torch.int32)                                              # [C]
+    out = torch.empty((c // 64, 8, 6, 8), dtype=torch.int32)
+    pc = pairs.reshape(c // 64, 8, 8, 5)                                                            # [step][chunk][ch][pair]
+    out[:, :, :5, :] = pc.permute(0, 1, 3, 2)
+    out[:, :, 5, :] = bias_bits.reshape(c // 64, 8, 8)
+    return out.reshape(-1)
+
+
+def dwpw_tile_order(h, w, dilation, tile=128):
+    """Visiting order of the 128-pixel tiles for AVL_OP_DWPW: sorted by the tile centre's position inside a period of
+    `dilation` image rows, so that tiles whose rows differ by a multiple of the dilation (they read the same input rows)
+    are neighbours and end up in flight on the same XCD."""
+    n = (h * w + tile - 1) // tile
+    period = dilation * w
+    keys = sorted(range(n), key=lambda t: ((tile * t + tile // 2) % period, t))
+    return torch.tensor(keys, dtype=torch.int32)
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -208,7 +237,7 @@ class SegNet(object):
 
     ROW_PAD = 256        # GEMM tiles read whole 128/256-row tiles
 
-    def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8):
+    def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8, fuse_dwpw=True):
         assert output_stride == 8, "the reference configuration is OS8 (base_cfg.py:106)"
         assert precision in ("bf16", "f16", "f32")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -217,6 +246,7 @@ class SegNet(object):
         self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[precision]
         self.avl_dtype = {"bf16": _lib.AVL_BF16, "f16": _lib.AVL_F16, "f32": _lib.AVL_F32}[precision]
         self.half = precision != "f32"              # 16-bit activations: MFMA stem / grouped-conv kernels
+        self.fuse_dwpw = bool(fuse_dwpw)            # ASPP branches: depthwise + pointwise as one kernel (16-bit types)
         self.num_classes = num_classes
         self._keep = []            # every tensor the plan points at
         self._free = {}            # numel -> [tensor] pool of released activation buffers
@@ -289,6 +319,24 @@ class SegNet(object):
             rp, rld, _ = self._view(res)
             f.update(in2=rp, in2_ld=rld)
         self._op(name, OP_GEMM, **f)
+
+    def _dwpw(self, name, src, hw, cin, w_dw, b_dw, w_pw, b_pw, dst, dst_col, dilation):
+        """DepthwiseSeparableConv2d (3x3 depthwise dil d pad d + BN + ReLU, 1x1 + BN + ReLU) as one op."""
+        h, wd = hw
+        cout = w_pw.shape[0]
+        w_rows = _round_up(cout, 256)
+        wp = torch.zeros((w_rows, cin), dtype=torch.float64)
+        wp[:cout] = w_pw.reshape(cout, cin)
+        bp = torch.zeros(w_rows, dtype=torch.float64)
+        bp[:cout] = b_pw
+        wdev, bdev = self._dev(wp, self.act_dtype), self._dev(bp, torch.float32)
+        params = torch.cat([pack_dw_pairs(w_dw, b_dw, self.act_dtype), dwpw_tile_order(h, wd, dilation)]).to(self.device)
+        self._keep.append(params)
+        ip, ild, irows = self._view(src)
+        op_, old, orows = self._view(dst, dst_col)
+        self._op(name, OP_DWPW, in_=ip, in2=params.data_ptr(), out=op_, weight=wdev.data_ptr(), bias=bdev.data_ptr(), in_h=h, in_w=wd,
+                 in_c=cin, in_ld=ild, in_rows=irows, out_h=h, out_w=wd, out_c=cout, out_ld=old, out_rows=orows, relu=1, w_rows=w_rows,
+                 ksize=3, stride=1, pad=dilation, dil=dilation, groups=cin)
 
     def _spatial(self, name, kind, src, in_hw, cin, dst, out_hw, cout, weight=None, bias=None, dst_col=0, **extra):
         ip, ild, irows = self._view(src)
@@ -408,13 +456,17 @@ class SegNet(object):
         for k in branches[1:]:
             p = "aspp.module_pyramid.%d" % k
             w, b = fold_bn(st, p + ".depthwise_cnn.conv.weight", p + ".depthwise_cnn.bn")
-            wd_, bd_ = self._dev(w.reshape(fc, 9).t().reshape(-1), torch.float32), self._dev(b, torch.float32)    # [tap][C]
-            t = self._act(M, fc)
-            self._spatial(p + ".depthwise_cnn", OP_DWCONV, feat, fhw, fc, t, fhw, fc, wd_, bd_, ksize=3, stride=1, pad=dil[k],
-                          dil=dil[k], groups=fc, relu=1, in2=self.zero_page.data_ptr())
-            w, b = fold_bn(st, p + ".pointwise_cnn.conv.weight", p + ".pointwise_cnn.bn")
-            self._gemm(p + ".pointwise_cnn", t, fhw, fc, w, b, cat, dst_col=col)
-            self._release(t)
+            w2, b2 = fold_bn(st, p + ".pointwise_cnn.conv.weight", p + ".pointwise_cnn.bn")
+            if self.half and self.fuse_dwpw and fc % 64 == 0 and fc <= 2048:
+                # depthwise + pointwise in one kernel: the 132 MB intermediate never goes to HBM (AVL_OP_DWPW)
+                self._dwpw(p, feat, fhw, fc, w, b, w2, b2, cat, col, dil[k])
+            else:
+                wd_, bd_ = self._dev(w.reshape(fc, 9).t().reshape(-1), torch.float32), self._dev(b, torch.float32)    # [tap][C]
+                t = self._act(M, fc)
+                self._spatial(p + ".depthwise_cnn", OP_DWCONV, feat, fhw, fc, t, fhw, fc, wd_, bd_, ksize=3, stride=1, pad=dil[k],
+                              dil=dil[k], groups=fc, relu=1, in2=self.zero_page.data_ptr())
+                self._gemm(p + ".pointwise_cnn", t, fhw, fc, w2, b2, cat, dst_col=col)
+                self._release(t)
             col += bch[k]
         # image pooling branch -> per-frame bias of the projection
         wg_, bg_ = fold_bn(st, "aspp.global_avg_pool.1.conv.weight", "aspp.global_avg_pool.1.bn")
