@@ -50,3 +50,29 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libavl_hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_hand_counted_kernels_do_not_spill(tmp_path):
+    """k_gemm_ring and k_dwpw wait for their LDS-DMA / buffer loads with hand-counted `s_waitcnt vmcnt(N)`.  A register
+    spill adds scratch loads and stores to the same in-order counter and silently breaks that arithmetic, so the build
+    must keep both kernels spill-free (checked on the compiler's own resource metadata)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.join(os.path.dirname(__file__), "..")
+    csrc = os.path.join(root, "vision_semantic_segmentation_amd", "csrc")
+    for src, kernels in (("seg_dwpw.hip", ("k_dwpw",)), ("seg_gemm.hip", ("k_gemm_ring",))):
+        out = os.path.join(str(tmp_path), src + ".s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(root, "include"), "-I" + csrc,
+                        "-S", "--cuda-device-only", "-o", out, os.path.join(csrc, src)], check=True, capture_output=True)
+        name, seen = None, 0
+        for line in open(out):
+            line = line.strip()
+            if line.startswith(".name:"):
+                name = line.split()[-1]
+            elif line.startswith(".vgpr_spill_count:") and name and any(k in name for k in kernels):
+                seen += 1
+                assert int(line.split()[-1]) == 0, "%s spills %s VGPRs" % (name, line.split()[-1])
+        assert seen > 0, "no %s kernel found in %s" % (kernels, src)
