@@ -33,7 +33,7 @@ struct DwPwArgs {
     const int* order;        // [mtiles] pixel-tile visited by the i-th workgroup slot (see launch_dwpw), behind the parameters
     int mtiles, per_xcd;
     void* C;
-    int H, Wd, ldx, ldc, M, N, K, dil, ntiles;
+    int H, Wd, OW, ldx, ldc, M, N, K, dil, pad, ntiles;      // input H x Wd, output rows are OW wide, M = OH * OW
     unsigned x_bytes;
 };
 
@@ -70,10 +70,10 @@ __global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int m = mt * TM + r0 + q * 64;
-        const int y = m / p.Wd, x = m - y * p.Wd;
+        const int y = m / p.OW, x = m - y * p.OW;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int iy = y + (t / 3 - 1) * p.dil, ix = x + (t % 3 - 1) * p.dil;
+            const int iy = y - p.pad + (t / 3) * p.dil, ix = x - p.pad + (t % 3) * p.dil;
             const bool ok = m < p.M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd;
             voff[q][t] = ok ? (unsigned)(((long long)iy * p.Wd + ix) * p.ldx + chunk * 8) * 2u : 0x7fffff00u;   // >= x_bytes: reads as 0
         }
@@ -268,13 +268,14 @@ int validate_dwpw(const avl_seg_op& op) {
     AVL_REQUIRE(is_half(op.dtype), "fused depthwise+pointwise needs a 16-bit activation type");
     AVL_REQUIRE(op.in && op.out && op.weight && op.bias && op.in2, "dwpw has NULL buffers");
     const int M = op.out_h * op.out_w, K = op.in_c, N = op.out_c;
-    AVL_REQUIRE(op.in_h == op.out_h && op.in_w == op.out_w && op.stride == 1 && op.ksize == 3 && op.dil >= 1 && op.pad == op.dil,
-                "dwpw geometry: 3x3, stride 1, pad == dilation (same-size output)");
+    AVL_REQUIRE(op.stride == 1 && op.ksize == 3 && op.dil >= 1 && op.pad >= 0 && op.out_h == op.in_h + 2 * op.pad - 2 * op.dil &&
+                    op.out_w == op.in_w + 2 * op.pad - 2 * op.dil && M > 0,
+                "dwpw geometry: 3x3, stride 1, output = input + 2 pad - 2 dilation");
     AVL_REQUIRE(K % 64 == 0 && K <= 2048, "dwpw K = %d (multiple of 64, <= 2048: the depthwise parameters live in LDS)", K);
     AVL_REQUIRE(N % 16 == 0 && op.w_rows >= (N + TN - 1) / TN * TN, "dwpw N = %d / weight rows %d", N, op.w_rows);
     AVL_REQUIRE(op.in_ld >= K && (op.in_ld * 2) % 16 == 0, "dwpw in_ld %d", op.in_ld);
     AVL_REQUIRE(op.out_ld >= N && (op.out_ld * 2) % 16 == 0, "dwpw out_ld %d", op.out_ld);
-    AVL_REQUIRE(op.in_rows >= M && op.out_rows >= M, "dwpw rows");
+    AVL_REQUIRE(op.in_rows >= op.in_h * op.in_w && op.out_rows >= M, "dwpw rows");
     AVL_REQUIRE((long long)op.in_rows * op.in_ld * 2 < 0x7fffff00LL, "dwpw input larger than a buffer descriptor's range");
     AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.in) | reinterpret_cast<uintptr_t>(op.weight) | reinterpret_cast<uintptr_t>(op.out) |
                  reinterpret_cast<uintptr_t>(op.bias) | reinterpret_cast<uintptr_t>(op.in2)) % 16 == 0, "dwpw buffers must be 16-byte aligned");
@@ -284,7 +285,7 @@ int validate_dwpw(const avl_seg_op& op) {
 int launch_dwpw(const avl_seg_op& op, hipStream_t s) {
     DwPwArgs a;
     a.X = op.in; a.W = op.weight; a.bias = op.bias; a.dwp = static_cast<const uint32_t*>(op.in2); a.C = op.out;
-    a.H = op.in_h; a.Wd = op.in_w; a.ldx = op.in_ld; a.ldc = op.out_ld;
+    a.H = op.in_h; a.Wd = op.in_w; a.OW = op.out_w; a.ldx = op.in_ld; a.ldc = op.out_ld; a.pad = op.pad;
     a.M = op.out_h * op.out_w; a.N = op.out_c; a.K = op.in_c; a.dil = op.dil;
     a.ntiles = (a.N + TN - 1) / TN;
     a.x_bytes = (unsigned)((long long)op.in_rows * op.in_ld * 2);

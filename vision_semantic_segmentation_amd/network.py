@@ -320,9 +320,11 @@ class SegNet(object):
             f.update(in2=rp, in2_ld=rld)
         self._op(name, OP_GEMM, **f)
 
-    def _dwpw(self, name, src, hw, cin, w_dw, b_dw, w_pw, b_pw, dst, dst_col, dilation):
-        """DepthwiseSeparableConv2d (3x3 depthwise dil d pad d + BN + ReLU, 1x1 + BN + ReLU) as one op."""
+    def _dwpw(self, name, src, hw, cin, w_dw, b_dw, w_pw, b_pw, dst, dst_col, dilation, padding=None):
+        """DepthwiseSeparableConv2d (3x3 depthwise dil d pad p + BN + ReLU, 1x1 + BN + ReLU) as one op."""
         h, wd = hw
+        padding = dilation if padding is None else padding
+        oh, ow = h + 2 * padding - 2 * dilation, wd + 2 * padding - 2 * dilation
         cout = w_pw.shape[0]
         w_rows = _round_up(cout, 256)
         wp = torch.zeros((w_rows, cin), dtype=torch.float64)
@@ -330,13 +332,13 @@ class SegNet(object):
         bp = torch.zeros(w_rows, dtype=torch.float64)
         bp[:cout] = b_pw
         wdev, bdev = self._dev(wp, self.act_dtype), self._dev(bp, torch.float32)
-        params = torch.cat([pack_dw_pairs(w_dw, b_dw, self.act_dtype), dwpw_tile_order(h, wd, dilation)]).to(self.device)
+        params = torch.cat([pack_dw_pairs(w_dw, b_dw, self.act_dtype), dwpw_tile_order(oh, ow, dilation)]).to(self.device)
         self._keep.append(params)
         ip, ild, irows = self._view(src)
         op_, old, orows = self._view(dst, dst_col)
         self._op(name, OP_DWPW, in_=ip, in2=params.data_ptr(), out=op_, weight=wdev.data_ptr(), bias=bdev.data_ptr(), in_h=h, in_w=wd,
-                 in_c=cin, in_ld=ild, in_rows=irows, out_h=h, out_w=wd, out_c=cout, out_ld=old, out_rows=orows, relu=1, w_rows=w_rows,
-                 ksize=3, stride=1, pad=dilation, dil=dilation, groups=cin)
+                 in_c=cin, in_ld=ild, in_rows=irows, out_h=oh, out_w=ow, out_c=cout, out_ld=old, out_rows=orows, relu=1, w_rows=w_rows,
+                 ksize=3, stride=1, pad=padding, dil=dilation, groups=cin)
 
     def _spatial(self, name, kind, src, in_hw, cin, dst, out_hw, cout, weight=None, bias=None, dst_col=0, **extra):
         ip, ild, irows = self._view(src)
@@ -510,15 +512,20 @@ class SegNet(object):
             p = "decoder.refine_layers.%d" % k
             ohw = (hw[0] - 2, hw[1] - 2)                                # padding 0 (decoder.py:33-36 default)
             w, b = fold_bn(st, p + ".depthwise_cnn.conv.weight", p + ".depthwise_cnn.bn")
-            wd_, bd_ = self._dev(w.reshape(cin, 9).t().reshape(-1), torch.float32), self._dev(b, torch.float32)
-            t = self._act(ohw[0] * ohw[1], cin)
-            self._spatial(p + ".depthwise_cnn", OP_DWCONV, x, hw, cin, t, ohw, cin, wd_, bd_, ksize=3, stride=1, pad=0, dil=1, groups=cin, relu=1,
-                          in2=self.zero_page.data_ptr())
-            self._release(x)
-            w, b = fold_bn(st, p + ".pointwise_cnn.conv.weight", p + ".pointwise_cnn.bn")
-            y = self._act(ohw[0] * ohw[1], w.shape[0])
-            self._gemm(p + ".pointwise_cnn", t, ohw, cin, w, b, y)
-            self._release(t)
+            w2, b2 = fold_bn(st, p + ".pointwise_cnn.conv.weight", p + ".pointwise_cnn.bn")
+            y = self._act(ohw[0] * ohw[1], w2.shape[0])
+            if self.half and self.fuse_dwpw and cin % 64 == 0 and cin <= 2048:
+                self._dwpw(p, x, hw, cin, w, b, w2, b2, y, 0, 1, padding=0)
+                self._release(x)
+            else:
+                wd_, bd_ = self._dev(w.reshape(cin, 9).t().reshape(-1), torch.float32), self._dev(b, torch.float32)
+                t = self._act(ohw[0] * ohw[1], cin)
+                self._spatial(p + ".depthwise_cnn", OP_DWCONV, x, hw, cin, t, ohw, cin, wd_, bd_, ksize=3, stride=1, pad=0, dil=1, groups=cin, relu=1,
+                              in2=self.zero_page.data_ptr())
+                self._release(x)
+                self._gemm(p + ".pointwise_cnn", t, ohw, cin, w2, b2, y)
+                self._release(t)
+            w = w2
             x, hw, cin = y, ohw, w.shape[0]
             k += 1
         p = "decoder.refine_layers.%d" % k
