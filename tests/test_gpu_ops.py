@@ -307,3 +307,50 @@ def test_fused_depthwise_pointwise(case, precision, cuda_device):
     got = _from_rows(out_b[:, 16:].cpu().float(), OH, OW, N)
     err = float((got - ref).abs().max() / ref.abs().max())
     assert err <= tol * 2, "dwpw %s %s: %.3e" % (case, precision, err)
+
+
+@pytest.mark.parametrize("case", [(180, 240, 2048, 12, 12), (270, 480, 512, 1, 0)])
+def test_fused_depthwise_pointwise_repeats_under_load(case, cuda_device):
+    """Race screen for AVL_OP_DWPW: the same launch, back to back with copies in between (a busy queue, like a graph
+    replay), must give the same bytes every time.  An earlier version that waited for inline-asm loads by hand passed
+    every parity test and was wrong a few times in a thousand launches at sizes with more tiles than CUs."""
+    import torch
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import OP_DWPW, AvlSegOp, dwpw_tile_order, pack_dw_pairs
+    H, W, K, d, pad = case
+    N = 256
+    g = torch.Generator().manual_seed(1)
+    OH, OW = H + 2 * pad - 2 * d, W + 2 * pad - 2 * d
+    M, Mi = OH * OW, H * W
+    Mp, Mip = (M + 255) // 256 * 256, (Mi + 255) // 256 * 256
+    x = torch.zeros((Mip, K), dtype=torch.bfloat16)
+    x[:Mi] = torch.randn((Mi, K), generator=g).to(torch.bfloat16)
+    w1, b1 = torch.randn((K, 1, 3, 3), generator=g).double() * 0.3, torch.randn(K, generator=g).double() * 0.1
+    xd = x.to(cuda_device)
+    w2d = (torch.randn((N, K), generator=g) / K ** 0.5).to(torch.bfloat16).to(cuda_device)
+    b2d = torch.randn(N, generator=g).to(cuda_device)
+    params = torch.cat([pack_dw_pairs(w1, b1, torch.bfloat16), dwpw_tile_order(OH, OW, d)]).to(cuda_device)
+    out = torch.zeros((Mp, N), dtype=torch.bfloat16, device=cuda_device)
+    op = AvlSegOp()
+    op.kind, op.dtype = OP_DWPW, _lib.AVL_BF16
+    op.in_, op.in2, op.out, op.weight, op.bias = xd.data_ptr(), params.data_ptr(), out.data_ptr(), w2d.data_ptr(), b2d.data_ptr()
+    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = H, W, K, K, Mip
+    op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = OH, OW, N, N, Mp
+    op.relu, op.w_rows, op.ksize, op.stride, op.pad, op.dil, op.groups = 1, N, 3, 1, pad, d, K
+    plan = C.c_void_p()
+    _lib.check(_lib.lib().avl_seg_plan_create((AvlSegOp * 1)(op), 1, C.byref(plan)), "avl_seg_plan_create")
+    try:
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.lib().avl_seg_plan_run(plan, s), "avl_seg_plan_run")
+        torch.cuda.synchronize()
+        ref = out.clone()
+        outs = [torch.zeros_like(out) for _ in range(4)]
+        for i in range(120):
+            _lib.lib().avl_seg_plan_run(plan, s)
+            outs[i % 4].copy_(out)
+            if i % 4 == 3:
+                torch.cuda.synchronize()
+                for o in outs:
+                    assert torch.equal(o, ref), "launch ~%d differs from the first one" % i
+    finally:
+        _lib.lib().avl_seg_plan_destroy(plan)

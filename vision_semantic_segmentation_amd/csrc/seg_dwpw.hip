@@ -7,12 +7,12 @@
 // 256 output channels; for every 64-channel K-step its 512 lanes compute the 128 x 64 slice of `a` on the vector ALUs
 // (9 taps, 16 outputs per lane, the same paired v_dot2c order as k_dwconv, so `a` is bit-identical to the unfused one),
 // write it into LDS in the swizzled layout the MFMA fragments are read from, and multiply it with the weight slice
-// that LDS-DMA brought in meanwhile.  `a` never exists in HBM.
-//   * taps: buffer_load_dwordx4 with a range-checked descriptor -- a tap outside the image gets an out-of-range
+// that was loaded meanwhile.  `a` never exists in HBM.
+//   * taps: buffer loads with a range-checked descriptor -- a tap outside the image gets an out-of-range
 //     offset and the hardware returns zeros (no pointer select, no zero page); the K-step advances the scalar offset;
+//   * the weight slice of the next step travels through registers as well (see load_w: one kind of load, in order);
 //   * depthwise weights/bias of all K-steps sit in LDS for the whole tile (K/64 x 1.5 KB <= 48 KB);
-//   * while the MFMAs of step s run, the taps of step s+1 are in flight and its `a` slice is computed: the kernel is
-//     VALU/L1-bound (~2k cycles per step per SIMD), the matrix work hides under it.
+//   * while the MFMAs of step s run, the taps of step s+2 are in flight and the `a` slice of step s+1 is computed.
 #include "seg_types.h"
 
 namespace avl {
@@ -55,7 +55,6 @@ __global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
     if (slot >= p.mtiles) return;
     const int mt = p.order[slot];
     const int nk = p.K / 64;
-    const unsigned lds_base = lds_addr(lds);
 
     // ---- depthwise parameters of every K-step -> LDS
     {
@@ -78,29 +77,28 @@ __global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
             voff[q][t] = ok ? (unsigned)(((long long)iy * p.Wd + ix) * p.ldx + chunk * 8) * 2u : 0x7fffff00u;   // >= x_bytes: reads as 0
         }
     }
-    // raw buffer descriptor {base, stride 0, num_records = bytes, 32-bit data format}: out-of-range offsets load zeros
-    v4i xres;
-    {
-        const unsigned long long xa = reinterpret_cast<unsigned long long>(p.X);
-        xres[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xa);
-        xres[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xa >> 32) & 0xffff);
-        xres[2] = __builtin_amdgcn_readfirstlane((int)p.x_bytes);
-        xres[3] = 0x00020000;
-    }
-
-    // ---- weight DMA sources (as in k_gemm_ring): lane -> (row of an 8-row group, physical 16-byte chunk)
-    const int srow = lane >> 3, schunk = lane & 7;
-    const char* w_src[4];
+    // ---- weight slice (256 rows x 128 B per K-step) through registers: lane -> 16-byte chunk (tid & 7) of rows
+    // (tid >> 3) + 64 i; the swizzle goes on the ds_write address.  (LDS-DMA was used first; mixing it with register loads
+    // on one vmcnt counter needs waits that also drain the tap loads: an `s_waitcnt vmcnt(N)` is only safe when N does not
+    // exceed the number of younger operations OF THE SAME KIND.)
+    const int wchunk = tid & 7, wrow0 = tid >> 3;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(p.W) + (long long)nt * TN * p.K * 2), 0, TN * p.K * 2, 0x00020000);
+    int w_voff[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (i * 8 + wave) * 8 + srow;
-        const int key = ((r >> 1) & 1) | (((r >> 4) & 3) << 1);
-        w_src[i] = static_cast<const char*>(p.W) + (long long)(nt * TN + r) * p.K * 2 + ((schunk ^ key) << 4);
-    }
-    auto issue_w = [&](int s) {
-        const unsigned base = lds_base + LDS_W + (s & 1) * W_STAGE + wave * 1024;
+    for (int i = 0; i < 4; ++i) w_voff[i] = (wrow0 + 64 * i) * p.K * 2 + wchunk * 16;
+    v4i wl[4];
+    auto load_w = [&](int s) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16_asm(w_src[i] + (long long)s * 128, base + i * 8 * 1024);
+        for (int i = 0; i < 4; ++i) wl[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff[i], s * 128, 0);
+    };
+    auto store_w = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = wrow0 + 64 * i;
+            const int key = ((r >> 1) & 1) | (((r >> 4) & 3) << 1);
+            *reinterpret_cast<v4i*>(lds + LDS_W + (s & 1) * W_STAGE + r * 128 + ((wchunk ^ key) << 4)) = wl[i];
+        }
     };
 
     // ---- consumer geometry (64 x 64 per wave, product transposed: a lane ends with 16 consecutive channels of a pixel)
@@ -130,27 +128,17 @@ __global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
     }
 
     v4i raw[2][9];
-    // The tap loads are issued from inline asm and waited for by hand (taps_ready): loads that stay in flight across
-    // the loop back-edge make hipcc fall back to vmcnt(0) in front of every use, which would expose their latency.
+    // Every load of the loop is a compiler-visible buffer load: hipcc's own s_waitcnt insertion counts them (in-order
+    // return), also across the loop back-edge.  Hand-placed waits on inline-asm loads were tried first and were WRONG a
+    // few times in 10^3 launches: the register allocator is free to copy an asm output (it believes the value is there
+    // as soon as the asm statement has executed), and it did copy the tap registers at the top of the loop body, before
+    // the data had landed.
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.X), 0, (int)p.x_bytes, 0x00020000);
     auto load_taps = [&](int s, int q) {
-        const int soff = __builtin_amdgcn_readfirstlane(s * 128);
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(raw[q][t]) : "v"(voff[q][t]), "s"(xres), "s"(soff) : "memory");
+        for (int t = 0; t < 9; ++t) raw[q][t] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)voff[q][t], s * 128, 0);
     };
-    // N = vector-memory operations issued after the taps of pixel q (they complete in issue order)
-    auto taps_ready = [&](int q, int younger) {
-#define AVL_TAPS_WAIT(N)                                                                                                         \
-    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                        \
-                 : "+v"(raw[q][0]), "+v"(raw[q][1]), "+v"(raw[q][2]), "+v"(raw[q][3]), "+v"(raw[q][4]), "+v"(raw[q][5]),          \
-                   "+v"(raw[q][6]), "+v"(raw[q][7]), "+v"(raw[q][8])                                                              \
-                 :: "memory")
-        if (younger >= 13) AVL_TAPS_WAIT(13);
-        else if (younger >= 9) AVL_TAPS_WAIT(9);
-        else if (younger >= 4) AVL_TAPS_WAIT(4);
-        else AVL_TAPS_WAIT(0);
-#undef AVL_TAPS_WAIT
-    };
+
     // depthwise 3x3 of K-step s for pixel q of this lane -> A ring slot s & 1 (tap pairs exactly as k_dwconv)
     auto produce_a = [&](int s, int q) {
         const uint32_t* pp = reinterpret_cast<const uint32_t*>(lds + LDS_P + s * P_STEP + chunk * (6 * 8 * 4));
@@ -181,29 +169,25 @@ __global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
         Vec8<HT>::store(dst, o);
     };
 
-    // ---- prologue: A(0), W(0); the taps of step 1 are requested AFTER the W(0) DMA (the counted waits rely on it)
+    // ---- prologue: taps and weights of slice 0 -> A(0), W(0) in LDS; then the taps of slice 1
     load_taps(0, 0);
     load_taps(0, 1);
+    load_w(0);
     __syncthreads();                 // parameters are in LDS
-    taps_ready(0, 0);
-    taps_ready(1, 0);
     produce_a(0, 0);
     produce_a(0, 1);
-    issue_w(0);
+    store_w(0);
     if (nk > 1) { load_taps(1, 0); load_taps(1, 1); }
 
-    // Step s: the MFMAs of slice s, the depthwise slice s+1 (its taps were requested a whole step ago) and, as each
-    // pixel's tap registers free up, the requests for slice s+2.  vmcnt counts in issue order:
-    //   top of step s : younger than the W(s) DMA are the 18 taps of slice s+1        -> vmcnt(18) = "W(s) landed"
-    //   pixel 0 of s+1: younger are pixel 1's 9 taps and the 4 DMA of W(s+1)          -> vmcnt(13)
-    //   pixel 1 of s+1: younger are the 4 DMA and pixel 0's 9 taps of slice s+2 (if any) -> vmcnt(13) / vmcnt(4)
+    // Step s: the MFMAs of slice s, the depthwise slice s+1 (its taps were requested a whole step ago), the weight slice
+    // s+1 (requested at the top of the step, written to LDS at its end) and, as each pixel's tap registers free up, the
+    // taps of slice s+2.  hipcc places the vmcnt waits (all loads are compiler-visible and return in issue order).
     // (one half of the depthwise work between the two MFMA groups measured 10 % faster than all of it after them)
     for (int s = 0; s < nk; ++s) {
         const bool more = s + 1 < nk, more2 = s + 2 < nk;
-        if (more) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own A(s) / W(s) writes are in LDS
         __builtin_amdgcn_s_barrier();
-        if (more) issue_w(s + 1);
+        if (more) load_w(s + 1);
         const char* base = lds;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -219,11 +203,11 @@ __global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
 #pragma unroll
                 for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<HT>::mfma(wa[nj], af[mi], acc[mi][nj]);
             if (more) {
-                taps_ready(kk, kk == 0 ? 13 : (more2 ? 13 : 4));
                 produce_a(s + 1, kk);
                 if (more2) load_taps(s + 2, kk);
             }
         }
+        if (more) store_w(s + 1);
     }
 
     // ---- epilogue: ReLU, convert, store (bias was the accumulators' start value)
