@@ -139,6 +139,23 @@ def test_hipgraph_replay_is_identical(state, cuda_device):
         assert torch.equal(net.logits, ref)
 
 
+def test_full_size_frame_repeats_under_graph_replay(state, cuda_device):
+    """1080 x 1920 (more 128-pixel tiles than CUs in the decoder): eager run and 30 hipGraph replays give the same logits
+    bit for bit.  (A hand-scheduled version of the fused depthwise+pointwise kernel failed exactly this, rarely.)"""
+    import torch
+    from vision_semantic_segmentation_amd.network import SegNet
+    net = SegNet(state, 1080, 1920, precision="bf16", device=cuda_device)
+    img = torch.from_numpy(np.random.default_rng(12).integers(0, 256, size=(1080, 1920, 3), dtype=np.uint8)).to(cuda_device)
+    net.forward(img)
+    torch.cuda.synchronize()
+    ref = net.logits.clone()
+    net.capture_graph()
+    for i in range(30):
+        net.forward(img)
+        torch.cuda.synchronize()
+        assert torch.equal(net.logits, ref), "replay %d differs" % i
+
+
 def test_config_a_640x480_against_oracle(state, cuda_device):
     """BASELINE configs[0] size: 640x480 frame (263 GFLOP) -- logits 19 x 116 x 156 as SURVEY 8a states."""
     rel, agree = _compare(state, "f32", 480, 640, cuda_device, seed=3)
