@@ -221,7 +221,18 @@ typedef struct avl_seg_op {
     int32_t w_layout;        /* GCONV: 0 = float [group][tap][ci][co] (direct kernel),
                                        1 = bf16 block-diagonal 32-channel windows [window][2][9][16][32] (MFMA kernel)
                                 STEM:  0 = float [7][7][3][64] (direct kernel), 1 = bf16 [4][6][16][32] (MFMA kernel)   */
-    int32_t reserved[2];
+    int32_t w_split;         /* "mixed" precision (AVL_F16 only): 1 = `weight` holds each folded weight as an f16 pair
+                                hi = f16(w), lo = f16(w - hi), packed per 64-wide K block in the order the kernel
+                                walks it (GEMM/DWPW: [n][K/64][hi 64 | lo 64], or [hi | lo | hi] when the input is
+                                split too; GCONV: 18 taps = 9 hi + 9 lo).  hi + lo carries ~22 significant bits:
+                                the MFMAs run on both parts and accumulate in fp32.                             */
+    int32_t reserved;
+    /* split activations (w_split modes): a tensor may be stored as TWO f16 planes of identical shape and stride,
+     * value = hi + lo.  NULL = the tensor is a single f16 plane.  in_lo: the GEMM / depthwise input's low plane;
+     * in2_lo: the residual's; out_lo: where the low part of the result goes (the op then rounds nothing away). */
+    const void* in_lo;
+    const void* in2_lo;
+    void* out_lo;
 } avl_seg_op;
 
 typedef struct avl_seg_plan avl_seg_plan;

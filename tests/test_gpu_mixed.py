@@ -1,0 +1,289 @@
+"""MODEL.PRECISION = "mixed": f16 MFMA with split (hi + lo) operands.
+
+A split tensor is two float16 planes whose sum carries ~22 significant bits; split weights are the pair
+hi = f16(w), lo = f16(w - hi).  Every kernel that takes them is run ALONE through avl_seg_plan_* and compared with a
+float64 evaluation of the same operator on the values the planes actually hold (hi + lo), so only the fp32
+accumulation order and the dropped lo x lo products (2^-22) differ: tolerance 3e-6 of max|ref|.
+Then the whole network: logits within 1e-3 of the torch-CPU fp32 oracle (north_star's bar) -- the mode bench.py times."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 3e-6
+
+
+def _run_plan(ops):
+    from test_gpu_ops import _run_plan as run
+    run(ops)
+
+
+def _split(x64):
+    import torch
+    hi = x64.to(torch.float16)
+    lo = (x64 - hi.double()).to(torch.float16)
+    return hi, lo
+
+
+def _pad_rows(t, rows):
+    import torch
+    out = torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype)
+    out[:t.shape[0]] = t
+    return out
+
+
+@pytest.mark.parametrize("case", [  # (M, K, N, A split, residual, residual split, out split, relu)
+    (2600, 128, 256, False, False, False, False, True),       # conv1-like, weights split only (2 passes), 256x128 ring
+    (2600, 128, 256, True, False, False, True, True),         # 3 passes, split output
+    (70000, 256, 512, False, True, True, True, True),         # conv3-like on the 256x256 ring: split residual + output
+    (70000, 512, 256, True, True, True, True, False),         # downsample-like (no ReLU), 3 passes
+    (4097, 1024, 512, True, True, False, True, True),         # single-plane residual, split output
+    (300, 2048, 1024, False, True, True, False, True),        # split residual, single-plane output
+    (777, 256, 19, True, False, False, False, False),         # the classifier: 3 passes in the small-N kernel, fp32 out
+    (1000, 64, 128, True, False, False, True, True),          # K = one block
+])
+def test_split_gemm(case, cuda_device):
+    import torch
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import OP_GEMM, AvlSegOp, pack_split_rows
+    M, K, N, a_split, res, r_split, o_split, relu = case
+    g = torch.Generator().manual_seed(M + K + N + int(a_split))
+    Mp, Np = (M + 255) // 256 * 256, (N + 255) // 256 * 256
+    a64 = torch.randn((M, K), generator=g, dtype=torch.float64)
+    a_hi, a_lo = _split(a64)
+    w64 = torch.zeros((Np, K), dtype=torch.float64)
+    w64[:N] = torch.randn((N, K), generator=g, dtype=torch.float64) / K ** 0.5
+    w_hi, w_lo = _split(w64)
+    b = torch.zeros(Np)
+    b[:N] = torch.randn(N, generator=g)
+    out_f32 = N == 19
+    a_val = a_hi.double() + (a_lo.double() if a_split else 0)
+    ref = a_val @ (w_hi.double() + w_lo.double())[:N].t() + b[:N].double()
+    if res:
+        r64 = torch.randn((M, N), generator=g, dtype=torch.float64)
+        r_hi, r_lo = _split(r64)
+        ref = ref + r_hi.double() + (r_lo.double() if r_split else 0)
+    if relu:
+        ref = torch.relu(ref)
+    planes = torch.stack([_pad_rows(a_hi, Mp), _pad_rows(a_lo, Mp)]).to(cuda_device)
+    wd = pack_split_rows(w64, 3 if a_split else 2).to(cuda_device)
+    bd = b.to(cuda_device)
+    out = torch.full((2, Mp, N), 7.0, dtype=torch.float32 if out_f32 else torch.float16, device=cuda_device)
+    op = AvlSegOp()
+    op.kind, op.dtype = OP_GEMM, _lib.AVL_F16
+    op.in_, op.out, op.weight, op.bias = planes[0].data_ptr(), out[0].data_ptr(), wd.data_ptr(), bd.data_ptr()
+    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = 1, M, K, K, Mp
+    op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = 1, M, N, N, Mp
+    op.relu, op.out_f32, op.w_rows, op.ksize, op.stride, op.dil, op.groups = int(relu), int(out_f32), Np, 1, 1, 1, 1
+    op.w_split = 1
+    if a_split:
+        op.in_lo = planes[1].data_ptr()
+    if o_split:
+        op.out_lo = out[1].data_ptr()
+    if res:
+        rd = torch.stack([_pad_rows(r_hi, Mp), _pad_rows(r_lo, Mp)]).to(cuda_device)
+        op.in2, op.in2_ld = rd[0].data_ptr(), N
+        if r_split:
+            op.in2_lo = rd[1].data_ptr()
+    _run_plan([op])
+    got = out[0, :M].cpu().double() + (out[1, :M].cpu().double() if o_split else 0)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    bar = TOL if (o_split or out_f32) else 2 ** -11 * 1.5              # a single f16 output plane rounds to 11 bits
+    assert err <= bar, "split gemm %s: %.3e" % (case, err)
+    assert torch.all(out[0, M:] == 7.0)
+    if o_split:
+        assert torch.all(out[1, M:] == 7.0)
+        # the planes are a proper split: hi is the rounded value, |lo| <= half an ulp of hi
+        assert float((out[1, :M].float().abs() - out[0, :M].float().abs() * 2 ** -11).max()) <= 1e-7
+    else:
+        assert torch.all(out[1] == 7.0)                                  # the low plane is not touched
+
+
+@pytest.mark.parametrize("case", [(23, 45, 128, 1, 1), (23, 45, 256, 2, 1), (30, 41, 512, 1, 2), (19, 67, 1024, 1, 4)])
+@pytest.mark.parametrize("out_split", [False, True])
+def test_split_grouped_conv(case, out_split, cuda_device):
+    import torch
+    import torch.nn.functional as F
+    from test_gpu_ops import _from_rows, _nhwc_rows, _spatial_op
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import OP_GCONV, pack_gconv_windows
+    H, W, width, s, d = case
+    G = 32
+    cg = width // G
+    g = torch.Generator().manual_seed(H * 77 + W + width)
+    x = torch.randn((1, width, H, W), generator=g).to(torch.float16)
+    w64 = torch.randn((width, cg, 3, 3), generator=g, dtype=torch.float64) * (2.0 / (cg * 9)) ** 0.5
+    b = torch.randn(width, generator=g) * 0.1
+    OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+    w_hi, w_lo = _split(w64)
+    ref = F.relu(F.conv2d(x.double(), w_hi.double() + w_lo.double(), b.double(), stride=s, padding=d, dilation=d, groups=G))
+    src = _nhwc_rows(x).to(cuda_device)
+    dst = torch.full((2, (OH * OW + 255) // 256 * 256, width), 7.0, dtype=torch.float16, device=cuda_device)
+    nwin = width // 32
+    wd = torch.cat([pack_gconv_windows(w_hi.double(), G).reshape(nwin, 2, 9, 16, 32),
+                    pack_gconv_windows(w_lo.double(), G).reshape(nwin, 2, 9, 16, 32)], dim=2).reshape(-1).to(torch.float16).to(cuda_device)
+    bd = b.to(cuda_device)
+    _run_plan([_spatial_op(OP_GCONV, _lib.AVL_F16, src, (H, W), width, dst[0], (OH, OW), width, weight=wd.data_ptr(), bias=bd.data_ptr(),
+                           ksize=3, stride=s, pad=d, dil=d, groups=G, relu=1, w_layout=1, w_split=1,
+                           out_lo=dst[1].data_ptr() if out_split else 0)])
+    got = _from_rows(dst[0].cpu().double(), OH, OW, width)
+    if out_split:
+        got = got + _from_rows(dst[1].cpu().double(), OH, OW, width)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= (TOL if out_split else 2 ** -11 * 1.5), "split grouped conv %s: %.3e" % (case, err)
+    assert torch.all(dst[0, OH * OW:] == 7.0)
+
+
+@pytest.mark.parametrize("case", [(37, 53, 128, 256, 12), (20, 31, 2048, 256, 24), (16, 16, 256, 512, 1)])
+def test_split_fused_depthwise_pointwise(case, cuda_device):
+    """AVL_OP_DWPW with split 1x1 weights and a split output (the ASPP branches of the mixed mode): the depthwise slice
+    is still rounded to f16 (as in the f16 mode), the 1x1 runs two passes and nothing is rounded away at the output."""
+    import torch
+    import torch.nn.functional as F
+    from test_gpu_ops import _from_rows, _nhwc_rows
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import OP_DWPW, AvlSegOp, dwpw_tile_order, pack_dw_pairs, pack_split_rows
+    H, W, K, N, d = case
+    g = torch.Generator().manual_seed(H * 31 + W + K + d)
+    x = torch.randn((1, K, H, W), generator=g).to(torch.float16)
+    w1 = torch.randn((K, 1, 3, 3), generator=g) * 0.3
+    b1 = torch.randn(K, generator=g) * 0.1
+    w2 = torch.randn((N, K), generator=g, dtype=torch.float64) / K ** 0.5
+    b2 = torch.randn(N, generator=g) * 0.1
+    M = H * W
+    Mp, Np = (M + 255) // 256 * 256, (N + 255) // 256 * 256
+    src = _nhwc_rows(x).to(cuda_device)
+    w2p = torch.zeros((Np, K), dtype=torch.float64)
+    w2p[:N] = w2
+    b2p = torch.zeros(Np)
+    b2p[:N] = b2
+    w2d, b2d = pack_split_rows(w2p, 2).to(cuda_device), b2p.to(cuda_device)
+    out = torch.full((2, Mp, N), 7.0, dtype=torch.float16, device=cuda_device)
+    params = torch.cat([pack_dw_pairs(w1.double(), b1.double(), torch.float16), dwpw_tile_order(H, W, d)]).to(cuda_device)
+    op = AvlSegOp()
+    op.kind, op.dtype = OP_DWPW, _lib.AVL_F16
+    op.in_, op.in2, op.out, op.out_lo = src.data_ptr(), params.data_ptr(), out[0].data_ptr(), out[1].data_ptr()
+    op.weight, op.bias, op.w_split = w2d.data_ptr(), b2d.data_ptr(), 1
+    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = H, W, K, K, src.shape[0]
+    op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = H, W, N, N, Mp
+    op.relu, op.w_rows, op.ksize, op.stride, op.pad, op.dil, op.groups = 1, Np, 3, 1, d, d, K
+    _run_plan([op])
+    a = F.relu(F.conv2d(x.float(), w1.to(torch.float16).float(), b1, padding=d, dilation=d, groups=K)).to(torch.float16).double()
+    w_hi, w_lo = _split(w2)
+    ref = F.relu(F.conv2d(a, (w_hi.double() + w_lo.double()).view(N, K, 1, 1), b2.double()))
+    got = _from_rows(out[0].cpu().double() + out[1].cpu().double(), H, W, N)
+    # the depthwise slice goes through fp32 dot2 chains before its f16 rounding: a one-ulp flip of an `a` element
+    # (2^-11 relative, one of K terms of comparable size) moves an output by ~2^-11 / sqrt(K)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= 4 * 2 ** -11 / K ** 0.5, "split dwpw %s: %.3e" % (case, err)
+    assert torch.all(out[:, M:] == 7.0)
+
+
+@pytest.mark.parametrize("case", [(37, 53, 64, 1, 0), (20, 31, 512, 1, 0), (9, 9, 64, 2, 2)])
+def test_split_depthwise_and_bilinear(case, cuda_device):
+    import torch
+    import torch.nn.functional as F
+    from test_gpu_ops import _from_rows, _nhwc_rows, _spatial_op
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import OP_BILINEAR, OP_DWCONV
+    H, W, Cc, d, pad = case
+    g = torch.Generator().manual_seed(H * 1000 + W + d)
+    x64 = torch.randn((1, Cc, H, W), generator=g, dtype=torch.float64)
+    x_hi, x_lo = _split(x64)
+    xv = x_hi.double() + x_lo.double()
+    w = torch.randn((Cc, 1, 3, 3), generator=g) * 0.3
+    b = torch.randn(Cc, generator=g) * 0.1
+    OH, OW = H + 2 * pad - 2 * d, W + 2 * pad - 2 * d
+    ref = F.relu(F.conv2d(xv, w.double(), b.double(), padding=pad, dilation=d, groups=Cc))
+    src = torch.stack([_nhwc_rows(x_hi), _nhwc_rows(x_lo)]).to(cuda_device)
+    dst = torch.full((2, (OH * OW + 255) // 256 * 256, Cc), 7.0, dtype=torch.float16, device=cuda_device)
+    wd = w.reshape(Cc, 9).t().contiguous().reshape(-1).to(cuda_device)
+    bd = b.to(cuda_device)
+    zero = torch.zeros(64, dtype=torch.uint8, device=cuda_device)
+    _run_plan([_spatial_op(OP_DWCONV, _lib.AVL_F16, src[0], (H, W), Cc, dst[0], (OH, OW), Cc, weight=wd.data_ptr(), bias=bd.data_ptr(),
+                           in2=zero.data_ptr(), ksize=3, stride=1, pad=pad, dil=d, groups=Cc, relu=1,
+                           in_lo=src[1].data_ptr(), out_lo=dst[1].data_ptr())])
+    got = _from_rows(dst[0].cpu().double() + dst[1].cpu().double(), OH, OW, Cc)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= TOL, "split depthwise %s: %.3e" % (case, err)
+    assert torch.all(dst[:, OH * OW:] == 7.0)
+    # bilinear x2 (align_corners) on the same split input
+    oh, ow = 2 * H, 2 * W
+    refb = F.interpolate(xv.float(), size=(oh, ow), mode="bilinear", align_corners=True).double()
+    dstb = torch.zeros((2, (oh * ow + 255) // 256 * 256, Cc), dtype=torch.float16, device=cuda_device)
+    _run_plan([_spatial_op(OP_BILINEAR, _lib.AVL_F16, src[0], (H, W), Cc, dstb[0], (oh, ow), Cc, in_lo=src[1].data_ptr(), out_lo=dstb[1].data_ptr())])
+    gotb = _from_rows(dstb[0].cpu().double() + dstb[1].cpu().double(), oh, ow, Cc)
+    errb = float((gotb - refb).abs().max() / refb.abs().max())
+    assert errb <= 3e-5, "split bilinear %s: %.3e" % (case, errb)          # fp32 interpolation weights (see test_bilinear_align_corners)
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_ring_gemm_with_residual_repeats_under_load(split, cuda_device):
+    """Race screen for k_gemm_ring (hand-counted vmcnt around inline-asm LDS-DMA next to compiler-visible residual loads
+    and stores): a conv3 + residual shape with more tiles than CUs, launched back to back with copies in between, must
+    give the same bytes every time -- plain f16 and the split (3-pass, split residual and output) variant."""
+    import torch
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import OP_GEMM, AvlSegOp, pack_split_rows
+    M, K, N = 256 * 300, 256, 512
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn((2, M, K), generator=g).to(torch.float16).to(cuda_device)
+    a[1] *= 2 ** -11
+    r = torch.randn((2, M, N), generator=g).to(torch.float16).to(cuda_device)
+    r[1] *= 2 ** -11
+    w64 = torch.randn((N, K), generator=g, dtype=torch.float64) / K ** 0.5
+    wd = (pack_split_rows(w64, 3) if split else w64.to(torch.float16)).to(cuda_device)
+    bd = torch.randn(N, generator=g).to(cuda_device)
+    out = torch.zeros((2, M, N), dtype=torch.float16, device=cuda_device)
+    op = AvlSegOp()
+    op.kind, op.dtype = OP_GEMM, _lib.AVL_F16
+    op.in_, op.out, op.weight, op.bias = a[0].data_ptr(), out[0].data_ptr(), wd.data_ptr(), bd.data_ptr()
+    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = 1, M, K, K, M
+    op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = 1, M, N, N, M
+    op.relu, op.w_rows, op.ksize, op.stride, op.dil, op.groups = 1, N, 1, 1, 1, 1
+    op.in2, op.in2_ld = r[0].data_ptr(), N
+    if split:
+        op.w_split, op.in_lo, op.in2_lo, op.out_lo = 1, a[1].data_ptr(), r[1].data_ptr(), out[1].data_ptr()
+    plan = C.c_void_p()
+    _lib.check(_lib.lib().avl_seg_plan_create((AvlSegOp * 1)(op), 1, C.byref(plan)), "avl_seg_plan_create")
+    try:
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.lib().avl_seg_plan_run(plan, s), "avl_seg_plan_run")
+        torch.cuda.synchronize()
+        ref = out.clone()
+        outs = [torch.zeros_like(out) for _ in range(4)]
+        for i in range(80):
+            _lib.lib().avl_seg_plan_run(plan, s)
+            outs[i % 4].copy_(out)
+            if i % 4 == 3:
+                torch.cuda.synchronize()
+                for o in outs:
+                    assert torch.equal(o, ref), "launch ~%d differs from the first one" % i
+    finally:
+        _lib.lib().avl_seg_plan_destroy(plan)
+
+
+def _cfg(precision):
+    from vision_semantic_segmentation_amd.config import get_network_cfg_defaults
+    cfg = get_network_cfg_defaults()
+    cfg.MODEL.PRECISION = precision
+    return cfg
+
+
+@pytest.fixture(scope="module")
+def state():
+    from vision_semantic_segmentation_amd.network import random_state_dict
+    return random_state_dict(0)
+
+
+@pytest.mark.parametrize("hw", [(96, 128), (320, 416), (480, 640)])
+def test_mixed_logits_within_1e3_of_oracle(state, hw, cuda_device):
+    """north_star: segmentation logits within 1e-3 (relative to max|logit|) of the reference's fp32 forward, in the mode
+    bench.py times (MODEL.PRECISION = "mixed")."""
+    from test_gpu_seg import _compare
+    rel, agree = _compare(state, "mixed", hw[0], hw[1], cuda_device)
+    print("mixed %dx%d: max rel err %.3e, argmax agreement %.5f" % (hw[0], hw[1], rel, agree))
+    assert rel <= 1e-3
+    assert agree >= 0.998

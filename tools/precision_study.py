@@ -97,13 +97,12 @@ def forward(st, image_u8, pol):
             idn = x
         x = conv(o, stage + ".conv3", p + ".conv3.weight", p + ".bn3", res=idn, out_role="t")
     feat = x
-    fa = rnd(feat, pol("aspp", "ta"))
     dils = (1, 12, 24, 36)
-    outs = [conv(fa, "aspp.b0", "aspp.module_pyramid.0.conv.weight", "aspp.module_pyramid.0.bn")]
+    outs = [conv(rnd(feat, pol("aspp.b0", "ta")), "aspp.b0", "aspp.module_pyramid.0.conv.weight", "aspp.module_pyramid.0.bn")]
     for i in (1, 2, 3):
         pp = "aspp.module_pyramid.%d" % i
         c = feat.shape[1]
-        t = conv(fa, "aspp.b%d.dw" % i, pp + ".depthwise_cnn.conv.weight", pp + ".depthwise_cnn.bn", padding=dils[i], dilation=dils[i], groups=c)
+        t = conv(rnd(feat, pol("aspp.b%d.dw" % i, "ta")), "aspp.b%d.dw" % i, pp + ".depthwise_cnn.conv.weight", pp + ".depthwise_cnn.bn", padding=dils[i], dilation=dils[i], groups=c)
         outs.append(conv(t, "aspp.b%d.pw" % i, pp + ".pointwise_cnn.conv.weight", pp + ".pointwise_cnn.bn"))
     g = F.adaptive_avg_pool2d(feat, (1, 1))
     g = NO.conv2d_block(g, st, "aspp.global_avg_pool.1")
@@ -152,6 +151,60 @@ def main():
         report("S2 + dec a exact, t f16 everywhere", Policy("f16", **{":w": X, "dec:a": "f32"}))
         for st_ in ("dec.up", "dec.r0.dw", "dec.r0.pw", "dec.r1.dw", "dec.r1.pw", "dec.low"):
             report("S2 + %s a exact" % st_, Policy("f16", **{":w": X, ":t": "f32", st_ + ":a": "f32"}))
+    if sel == "v":
+        base = {":w": X, ":t": "f32", "dec:a": "f32", "aspp:a": "f32"}
+        report("V1: S2 + dec,aspp a exact", Policy("f16", **base))
+        report("V2: V1 + l3/l4 ta exact", Policy("f16", **dict(base, **{"layer3:ta": "f32", "layer4:ta": "f32"})))
+        report("V3: V1 + l1/l2 ta exact", Policy("f16", **dict(base, **{"layer1:ta": "f32", "layer2:ta": "f32"})))
+        report("V4: V1 + all ta exact", Policy("f16", **dict(base, **{":ta": "f32"})))
+        d5 = dict(base, **{":ta": "f32"})
+        for li, nb in ((1, 3), (2, 4), (3, 6), (4, 3)):
+            for b in range(nb):
+                d5["layer%d.%d.conv2:a" % (li, b)] = "f32"
+        report("V5: V4 + conv2 out exact", Policy("f16", **d5))
+        d6 = dict(base, **{":ta": "f32"})
+        for li, nb in ((1, 3), (2, 4), (3, 6), (4, 3)):
+            for b in range(nb):
+                d6["layer%d.%d.conv1:a" % (li, b)] = "f32"
+        report("V6: V4 + conv1 out exact", Policy("f16", **d6))
+        report("V7: V4 but aspp a f16", Policy("f16", **{":w": X, ":t": "f32", "dec:a": "f32", ":ta": "f32"}))
+        report("V8: V4 but stem exact too", Policy("f16", **dict(base, **{":ta": "f32", "stem": "f32"})))
+    if sel == "v9":
+        d = {":w": X, ":t": "f32", ":ta": "f32", "stem": "f16", "dec": "f32", "dec:w": X,
+             "aspp.b0:a": "f32", "aspp.proj:a": "f32"}
+        for i in (1, 2, 3):
+            d["aspp.b%d.dw" % i] = "f16"          # reads hi only, f16 depthwise weights, f16 A tile
+            d["aspp.b%d.pw:a" % i] = "f32"        # split output
+        report("V9: the scheme to build", Policy("f16", **d))
+        report("V9 + stem w x2", Policy("f16", **dict(d, **{"stem:w": X})))
+        d2 = dict(d)
+        for i in (1, 2, 3):
+            d2["aspp.b%d.dw:ta" % i] = "f32"
+        report("V9 + aspp dw reads split", Policy("f16", **d2))
+        report("V9 but dec dw weights f16", Policy("f16", **dict(d, **{"dec.r0.dw:w": "f16", "dec.r1.dw:w": "f16"})))
+    if sel == "c":
+        c1 = {":w": X, ":t": "f32", "stem": "f16", "dec": "f32", "dec:w": X, "dec.low:ta": "f32",
+              "aspp.b0:a": "f32", "aspp.b0:ta": "f32", "aspp.proj:a": "f32"}
+        for i in (1, 2, 3):
+            c1["aspp.b%d.dw" % i] = "f16"
+            c1["aspp.b%d.pw:a" % i] = "f32"
+        report("C1: S2 + aspp/dec exact (conv1 reads hi)", Policy("f16", **c1))
+        c2 = dict(c1, **{"layer3:ta": "f32", "layer4:ta": "f32"})
+        report("C2: C1 + l3/l4 conv1,down read split", Policy("f16", **c2))
+        c3 = dict(c1)
+        c4 = dict(c1)
+        for li, nb in ((3, 6), (4, 3)):
+            for b in range(nb):
+                c3["layer%d.%d.conv2:a" % (li, b)] = "f32"
+                c4["layer%d.%d.conv1:a" % (li, b)] = "f32"
+        report("C3: C1 + l3/l4 conv2 out split", Policy("f16", **c3))
+        report("C4: C1 + l3/l4 conv1 out split", Policy("f16", **c4))
+        c5 = dict(c3)
+        for li, nb in ((1, 3), (2, 4)):
+            for b in range(nb):
+                c5["layer%d.%d.conv2:a" % (li, b)] = "f32"
+        report("C5: C3 + l1/l2 conv2 out split", Policy("f16", **c5))
+        report("C6: C2 + C3", Policy("f16", **dict(c3, **{"layer3:ta": "f32", "layer4:ta": "f32"})))
     print("den (max|logit|) = %.3f" % den)
 
 

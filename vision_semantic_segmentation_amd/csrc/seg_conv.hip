@@ -283,9 +283,10 @@ __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, c
 
 // ------------------------------------------------------------------------------------- bilinear
 // F.interpolate(mode='bilinear', align_corners=True): src = dst * (in-1)/(out-1)
+// in_lo / out_lo ("mixed" precision, f16): optional low planes, value = hi + lo (exact in fp32).
 template <typename T>
-__global__ void __launch_bounds__(kThreads) k_bilinear(const T* __restrict__ in, int H, int W, int C, int in_ld,
-                                                      T* __restrict__ out, int OH, int OW, int out_ld) {
+__global__ void __launch_bounds__(kThreads) k_bilinear(const T* __restrict__ in, const T* __restrict__ in_lo, int H, int W, int C, int in_ld,
+                                                      T* __restrict__ out, T* __restrict__ out_lo, int OH, int OW, int out_ld) {
     const int c8n = C / 8;
     const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
     if (idx >= (long long)OH * OW * c8n) return;
@@ -298,13 +299,80 @@ __global__ void __launch_bounds__(kThreads) k_bilinear(const T* __restrict__ in,
     const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
     const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
     float a[8], b[8], c[8], d[8], r[8];
-    Vec8<T>::load(in + ((long long)y0 * W + x0) * in_ld + c8 * 8, a);
-    Vec8<T>::load(in + ((long long)y0 * W + x1) * in_ld + c8 * 8, b);
-    Vec8<T>::load(in + ((long long)y1 * W + x0) * in_ld + c8 * 8, c);
-    Vec8<T>::load(in + ((long long)y1 * W + x1) * in_ld + c8 * 8, d);
+    const long long o00 = ((long long)y0 * W + x0) * in_ld + c8 * 8, o01 = ((long long)y0 * W + x1) * in_ld + c8 * 8;
+    const long long o10 = ((long long)y1 * W + x0) * in_ld + c8 * 8, o11 = ((long long)y1 * W + x1) * in_ld + c8 * 8;
+    Vec8<T>::load(in + o00, a);
+    Vec8<T>::load(in + o01, b);
+    Vec8<T>::load(in + o10, c);
+    Vec8<T>::load(in + o11, d);
+    if (in_lo) {
+        float al[8], bl[8], cl[8], dl[8];
+        Vec8<T>::load(in_lo + o00, al);
+        Vec8<T>::load(in_lo + o01, bl);
+        Vec8<T>::load(in_lo + o10, cl);
+        Vec8<T>::load(in_lo + o11, dl);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a[i] += al[i]; b[i] += bl[i]; c[i] += cl[i]; d[i] += dl[i]; }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = hy * (hx * a[i] + lx * b[i]) + ly * (hx * c[i] + lx * d[i]);
     Vec8<T>::store(out + (long long)pix * out_ld + c8 * 8, r);
+    if (out_lo) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] -= to_f32(from_f32<T>(r[i]));
+        Vec8<T>::store(out_lo + (long long)pix * out_ld + c8 * 8, r);
+    }
+}
+
+// Depthwise 3x3 on split (hi + lo) f16 planes, fp32 weights, fp32 FMA chain in tap order, split result: the "mixed"
+// precision decoder (its activations keep ~22 significant bits).  One lane = one output pixel x 8 channels; consecutive
+// lanes = consecutive channel chunks of a pixel.  A tap outside the image contributes zero.
+template <typename T>
+__global__ void __launch_bounds__(kThreads) k_dwconv_split(const T* __restrict__ in, const T* __restrict__ in_lo, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, T* __restrict__ out, T* __restrict__ out_lo,
+                                                          int H, int W, int C, int in_ld, int OH, int OW, int out_ld, int pad, int dil, int relu) {
+    const int c8n = C / 8;
+    const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= (long long)OH * OW * c8n) return;
+    const int c8 = (int)(idx % c8n);
+    const int pix = (int)(idx / c8n), oy = pix / OW, ox = pix % OW;
+    float acc[8];
+    {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + c8 * 8), b1 = *reinterpret_cast<const float4*>(bias + c8 * 8 + 4);
+        acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+    }
+    float xv[9][8];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = oy - pad + (t / 3) * dil, ix = ox - pad + (t % 3) * dil;
+        ok[t] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const long long o = ok[t] ? ((long long)iy * W + ix) * in_ld + c8 * 8 : (long long)c8 * 8;
+        Vec8<T>::load(in + o, xv[t]);
+        if (in_lo) {
+            float l[8];
+            Vec8<T>::load(in_lo + o, l);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xv[t][i] += l[i];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float4 w0 = *reinterpret_cast<const float4*>(w + t * C + c8 * 8), w1 = *reinterpret_cast<const float4*>(w + t * C + c8 * 8 + 4);
+        const float wt[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(ok[t] ? xv[t][i] : 0.f, wt[i], acc[i]);
+    }
+    if (relu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaxf(acc[i], 0.f);
+    }
+    Vec8<T>::store(out + (long long)pix * out_ld + c8 * 8, acc);
+    if (out_lo) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] -= to_f32(from_f32<T>(acc[i]));
+        Vec8<T>::store(out_lo + (long long)pix * out_ld + c8 * 8, acc);
+    }
 }
 
 // ---------------------------------------------------------------------------- global average pool
@@ -496,6 +564,12 @@ int launch_typed(const avl_seg_op& op, hipStream_t s) {
             break;
         }
         case AVL_OP_DWCONV: {
+            if (op.in_lo || op.out_lo) {
+                hipLaunchKernelGGL(k_dwconv_split<T>, dim3(blocks_for((long long)op.out_h * op.out_w * (op.in_c / 8))), dim3(kThreads), 0, s,
+                                   in, static_cast<const T*>(op.in_lo), w, op.bias, out, static_cast<T*>(op.out_lo), op.in_h, op.in_w,
+                                   op.in_c, op.in_ld, op.out_h, op.out_w, op.out_ld, op.pad, op.dil, op.relu);
+                break;
+            }
             DwGeom g;
             g.H = op.in_h; g.W = op.in_w; g.C = op.in_c; g.in_ld = op.in_ld; g.OH = op.out_h; g.OW = op.out_w; g.out_ld = op.out_ld;
             g.pad = op.pad; g.dil = op.dil; g.relu = op.relu;
@@ -531,7 +605,8 @@ int launch_typed(const avl_seg_op& op, hipStream_t s) {
         }
         case AVL_OP_BILINEAR:
             hipLaunchKernelGGL(k_bilinear<T>, dim3(blocks_for((long long)op.out_h * op.out_w * (op.in_c / 8))), dim3(kThreads), 0, s,
-                               in, op.in_h, op.in_w, op.in_c, op.in_ld, out, op.out_h, op.out_w, op.out_ld);
+                               in, static_cast<const T*>(op.in_lo), op.in_h, op.in_w, op.in_c, op.in_ld, out, static_cast<T*>(op.out_lo),
+                               op.out_h, op.out_w, op.out_ld);
             break;
         case AVL_OP_GAP: {
             const int G = 256;
@@ -586,6 +661,13 @@ int validate_conv_op(const avl_seg_op& op) {
     AVL_REQUIRE(op.in_ld >= op.in_c && op.out_ld >= op.out_c, "op %d: leading dims", op.kind);
     AVL_REQUIRE((op.in_ld * es) % 16 == 0 && (op.out_ld * es) % 16 == 0, "op %d: row strides must be 16-byte multiples", op.kind);
     AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.in) | reinterpret_cast<uintptr_t>(op.out)) % 16 == 0, "op %d: unaligned buffers", op.kind);
+    if (op.in_lo || op.out_lo || op.in2_lo) {
+        // split (hi + lo) planes: same shape and stride as the high plane; f16 only
+        AVL_REQUIRE(op.dtype == AVL_F16 && !op.in2_lo, "op %d: split planes need AVL_F16 (and no in2_lo)", op.kind);
+        AVL_REQUIRE(op.kind == AVL_OP_BILINEAR || op.kind == AVL_OP_DWCONV || (op.kind == AVL_OP_GCONV && op.w_layout == 1),
+                    "op %d does not take split planes", op.kind);
+        AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.in_lo) | reinterpret_cast<uintptr_t>(op.out_lo)) % 16 == 0, "op %d: unaligned low planes", op.kind);
+    }
     switch (op.kind) {
         case AVL_OP_MAXPOOL:
             AVL_REQUIRE(op.out_c == op.in_c && op.out_h == (op.in_h + 2 - 3) / 2 + 1 && op.out_w == (op.in_w + 2 - 3) / 2 + 1, "maxpool shapes");

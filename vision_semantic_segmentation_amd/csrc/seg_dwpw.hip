@@ -33,13 +33,17 @@ struct DwPwArgs {
     const int* order;        // [mtiles] pixel-tile visited by the i-th workgroup slot (see launch_dwpw), behind the parameters
     int mtiles, per_xcd;
     void* C;
+    void* C_lo;              // "mixed" precision: low plane of the result (value - f16(value)), or NULL
     int H, Wd, OW, ldx, ldc, M, N, K, dil, pad, ntiles;      // input H x Wd, output rows are OW wide, M = OH * OW
     unsigned x_bytes;
 };
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-template <typename HT>
+// WSUB = 2 ("mixed" precision): the 1x1 weights come as f16 pairs, rows [K/64][hi 64 | lo 64]; every K-step then has
+// two MFMA passes over the same depthwise slice (hi weights, lo weights), and the depthwise work of the next slice is
+// split between them (pixel q = 0 during the first, q = 1 during the second).
+template <typename HT, int WSUB = 1>
 __global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
     typedef typename Half16<HT>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -83,10 +87,10 @@ __global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
     // exceed the number of younger operations OF THE SAME KIND.)
     const int wchunk = tid & 7, wrow0 = tid >> 3;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(static_cast<const char*>(p.W) + (long long)nt * TN * p.K * 2), 0, TN * p.K * 2, 0x00020000);
+        const_cast<char*>(static_cast<const char*>(p.W) + (long long)nt * TN * p.K * (2 * WSUB)), 0, TN * p.K * (2 * WSUB), 0x00020000);
     int w_voff[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w_voff[i] = (wrow0 + 64 * i) * p.K * 2 + wchunk * 16;
+    for (int i = 0; i < 4; ++i) w_voff[i] = (wrow0 + 64 * i) * p.K * (2 * WSUB) + wchunk * 16;
     v4i wl[4];
     auto load_w = [&](int s) {
 #pragma unroll
@@ -183,18 +187,20 @@ __global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
     // s+1 (requested at the top of the step, written to LDS at its end) and, as each pixel's tap registers free up, the
     // taps of slice s+2.  hipcc places the vmcnt waits (all loads are compiler-visible and return in issue order).
     // (one half of the depthwise work between the two MFMA groups measured 10 % faster than all of it after them)
-    for (int s = 0; s < nk; ++s) {
-        const bool more = s + 1 < nk, more2 = s + 2 < nk;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own A(s) / W(s) writes are in LDS
+    // (load_w / store_w count weight sub-slices h = s * WSUB + j; the ring slot of sub-slice h is h & 1)
+    for (int h = 0; h < nk * WSUB; ++h) {
+        const int s = h / WSUB, j = h % WSUB;
+        const bool more = s + 1 < nk, more2 = s + 2 < nk, morew = h + 1 < nk * WSUB;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own A(s) / W(h) writes are in LDS
         __builtin_amdgcn_s_barrier();
-        if (more) load_w(s + 1);
+        if (morew) load_w(h + 1);
         const char* base = lds;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             v8 wa[4], af[4];
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj)
-                wa[nj] = *reinterpret_cast<const v8*>(base + (s & 1) * W_STAGE + w_off[nj] + (((kk * 4 + kq) ^ w_key[nj]) << 4));
+                wa[nj] = *reinterpret_cast<const v8*>(base + (h & 1) * W_STAGE + w_off[nj] + (((kk * 4 + kq) ^ w_key[nj]) << 4));
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
                 af[mi] = *reinterpret_cast<const v8*>(base + (s & 1) * A_STAGE + a_off[mi] + (((kk * 4 + kq) ^ a_key[mi]) << 4));
@@ -202,12 +208,12 @@ __global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<HT>::mfma(wa[nj], af[mi], acc[mi][nj]);
-            if (more) {
+            if (more && (WSUB == 1 || kk == j)) {
                 produce_a(s + 1, kk);
                 if (more2) load_taps(s + 2, kk);
             }
         }
-        if (more) store_w(s + 1);
+        if (morew) store_w(h + 1);
     }
 
     // ---- epilogue: ReLU, convert, store (bias was the accumulators' start value)
@@ -228,20 +234,25 @@ __global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
                 HT* cp = static_cast<HT*>(p.C) + (long long)m * p.ldc + nbase;
                 Vec8<HT>::store(cp, lo);
                 Vec8<HT>::store(cp + 8, hi);
+                if constexpr (WSUB != 1) {
+                    if (p.C_lo) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { lo[i] -= (float)(HT)lo[i]; hi[i] -= (float)(HT)hi[i]; }
+                        HT* cl = static_cast<HT*>(p.C_lo) + (long long)m * p.ldc + nbase;
+                        Vec8<HT>::store(cl, lo);
+                        Vec8<HT>::store(cl + 8, hi);
+                    }
+                }
             }
         }
     }
 }
 
-template <typename HT>
+template <typename HT, int WSUB>
 int launch_dwpw_typed(const DwPwArgs& a, int mtiles, hipStream_t s) {
     const int lds_bytes = LDS_P + (a.K / 64) * P_STEP;
-    static bool attr = false;
-    if (!attr) {
-        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw<HT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
-    hipLaunchKernelGGL(k_dwpw<HT>, dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
+    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw<HT, WSUB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL((k_dwpw<HT, WSUB>), dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
@@ -251,6 +262,9 @@ int launch_dwpw_typed(const DwPwArgs& a, int mtiles, hipStream_t s) {
 int validate_dwpw(const avl_seg_op& op) {
     AVL_REQUIRE(is_half(op.dtype), "fused depthwise+pointwise needs a 16-bit activation type");
     AVL_REQUIRE(op.in && op.out && op.weight && op.bias && op.in2, "dwpw has NULL buffers");
+    AVL_REQUIRE(!op.w_split || op.dtype == AVL_F16, "split weights need AVL_F16 activations");
+    AVL_REQUIRE(!op.in_lo && !op.in2_lo && (!op.out_lo || op.w_split), "dwpw: only the output may be split, and only with w_split");
+    AVL_REQUIRE(reinterpret_cast<uintptr_t>(op.out_lo) % 16 == 0, "dwpw low plane must be 16-byte aligned");
     const int M = op.out_h * op.out_w, K = op.in_c, N = op.out_c;
     AVL_REQUIRE(op.stride == 1 && op.ksize == 3 && op.dil >= 1 && op.pad >= 0 && op.out_h == op.in_h + 2 * op.pad - 2 * op.dil &&
                     op.out_w == op.in_w + 2 * op.pad - 2 * op.dil && M > 0,
@@ -277,7 +291,9 @@ int launch_dwpw(const avl_seg_op& op, hipStream_t s) {
     a.mtiles = mtiles;
     a.per_xcd = (mtiles + 7) / 8;
     a.order = reinterpret_cast<const int*>(a.dwp + (a.K / 64) * (P_STEP / 4));
-    return op.dtype == AVL_F16 ? launch_dwpw_typed<f16>(a, mtiles, s) : launch_dwpw_typed<bf16>(a, mtiles, s);
+    a.C_lo = op.out_lo;
+    if (op.w_split) return launch_dwpw_typed<f16, 2>(a, mtiles, s);
+    return op.dtype == AVL_F16 ? launch_dwpw_typed<f16, 1>(a, mtiles, s) : launch_dwpw_typed<bf16, 1>(a, mtiles, s);
 }
 
 }  // namespace avl

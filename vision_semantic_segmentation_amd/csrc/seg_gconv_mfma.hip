@@ -26,6 +26,7 @@ struct GconvArgs {
     const HT* w;          // [window][nj 2][tap 9][i 16][ci 32]
     const float* bias;   // [C]
     HT* out;
+    HT* out_lo;          // "mixed" precision: low plane of the result (value - f16(value)), or NULL
     int H, W, in_ld, OH, OW, out_ld, C;
     int stride, dil;
     int th;              // output tile height (8, or 4 for stride 2)
@@ -33,7 +34,9 @@ struct GconvArgs {
     int comb;            // 1: stride 1, dilation d > 1 -> tiles live on the d x d residue-class grids (see below)
 };
 
-template <typename HT>
+// WS = 1 ("mixed" precision): the weights come as f16 pairs hi + lo ([window][nj 2][tap 18 = 9 hi, 9 lo][16][32]); both
+// parts multiply the same input fragment into the same accumulator (fp32), i.e. the weights keep ~22 significant bits.
+template <typename HT, int WS = 0>
 __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs<HT> p) {
     typedef typename Half16<HT>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -89,14 +92,15 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs<HT> p) {
     const int win = wave & 1;                  // window inside the 64-channel chunk
     const int half = wave >> 1;                // which half of the tile's sub-tiles
     const int fr = lane & 15, kq = lane >> 4;
-    v8 wf[2][9];
+    constexpr int NT = WS ? 18 : 9;
+    v8 wf[2][NT];
     {
-        const HT* wp = p.w + (long long)(cchunk * 2 + win) * (2 * 9 * 16 * 32);
+        const HT* wp = p.w + (long long)(cchunk * 2 + win) * (2 * NT * 16 * 32);
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
-                wf[nj][t] = *reinterpret_cast<const v8*>(wp + ((nj * 9 + t) * 16 + fr) * 32 + kq * 8);
+            for (int t = 0; t < NT; ++t)
+                wf[nj][t] = *reinterpret_cast<const v8*>(wp + ((nj * NT + t) * 16 + fr) * 32 + kq * 8);
     }
     // lane's 8 output channels: window base + q*8 + nj*4 + r
     const int cbase = c0 + win * 32 + kq * 8;
@@ -127,6 +131,10 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs<HT> p) {
         for (int t = 0; t < 9; ++t) {
             acc0 = Half16<HT>::mfma(wf[0][t], a[t], acc0);
             acc1 = Half16<HT>::mfma(wf[1][t], a[t], acc1);
+            if constexpr (WS != 0) {
+                acc0 = Half16<HT>::mfma(wf[0][9 + t], a[t], acc0);
+                acc1 = Half16<HT>::mfma(wf[1][9 + t], a[t], acc1);
+            }
         }
         const int oy = ry + (oy0 + sy) * step, ox = rx + (ox0 + sx) * step;
         if (oy < p.OH && ox < p.OW) {
@@ -137,6 +145,13 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs<HT> p) {
                 v[4 + r] = fmaxf(acc1[r] + bias[4 + r], 0.f);
             }
             Vec8<HT>::store(p.out + ((long long)oy * p.OW + ox) * p.out_ld + cbase, v);
+            if constexpr (WS != 0) {
+                if (p.out_lo) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] -= (float)(HT)v[r];
+                    Vec8<HT>::store(p.out_lo + ((long long)oy * p.OW + ox) * p.out_ld + cbase, v);
+                }
+            }
         }
     }
 }
@@ -149,13 +164,14 @@ int gconv_mfma_lds_bytes(int stride, int dil, int& th) {
     return ((in_th * in_tw + 7) / 8) * 1024;      // whole 8-pixel DMA groups
 }
 
-template <typename HT>
+template <typename HT, int WS>
 int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
     GconvArgs<HT> a;
     a.in = static_cast<const HT*>(op.in);
     a.w = static_cast<const HT*>(op.weight);
     a.bias = op.bias;
     a.out = static_cast<HT*>(op.out);
+    a.out_lo = static_cast<HT*>(op.out_lo);
     a.H = op.in_h; a.W = op.in_w; a.in_ld = op.in_ld; a.OH = op.out_h; a.OW = op.out_w; a.out_ld = op.out_ld; a.C = op.in_c;
     a.stride = op.stride; a.dil = op.dil;
     a.comb = (op.stride == 1 && op.dil > 1 && op.pad == op.dil) ? 1 : 0;
@@ -165,23 +181,22 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
     a.tiles_y = (gh + a.th - 1) / a.th;
     a.cchunks = op.in_c / CC;
     const int ncomb = a.comb ? op.dil * op.dil : 1;
-    static bool attr = false;
-    if (!attr) {
-        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv_mfma<HT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
-    hipLaunchKernelGGL(k_gconv_mfma<HT>, dim3(a.tiles_x * a.tiles_y * a.cchunks * ncomb), dim3(256), ldsb, s, a);
+    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv_mfma<HT, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL((k_gconv_mfma<HT, WS>), dim3(a.tiles_x * a.tiles_y * a.cchunks * ncomb), dim3(256), ldsb, s, a);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
 
 int launch_gconv_mfma(const avl_seg_op& op, hipStream_t s) {
-    return op.dtype == AVL_F16 ? launch_gconv_typed<f16>(op, s) : launch_gconv_typed<bf16>(op, s);
+    if (op.w_split) return launch_gconv_typed<f16, 1>(op, s);
+    return op.dtype == AVL_F16 ? launch_gconv_typed<f16, 0>(op, s) : launch_gconv_typed<bf16, 0>(op, s);
 }
 
 int validate_gconv_mfma(const avl_seg_op& op) {
     AVL_REQUIRE(is_half(op.dtype), "MFMA grouped conv needs a 16-bit activation type");
     AVL_REQUIRE(op.in_c % CC == 0, "MFMA grouped conv needs channels %% 64 == 0 (got %d)", op.in_c);
+    AVL_REQUIRE(!op.w_split || op.dtype == AVL_F16, "split weights need AVL_F16 activations");
+    AVL_REQUIRE(!op.in_lo && !op.in2_lo && (!op.out_lo || op.w_split), "grouped conv: only the output may be split, and only with w_split");
     const int cg = op.in_c / op.groups;
     AVL_REQUIRE(cg <= 32 && 32 % cg == 0, "MFMA grouped conv needs <= 32 channels per group dividing 32 (got %d)", cg);
     int th;

@@ -40,7 +40,8 @@ class AvlSegOp(C.Structure):
         ("out_h", C.c_int32), ("out_w", C.c_int32), ("out_c", C.c_int32), ("out_ld", C.c_int32), ("out_rows", C.c_int32),
         ("in2_ld", C.c_int32),
         ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32), ("groups", C.c_int32),
-        ("relu", C.c_int32), ("out_f32", C.c_int32), ("w_rows", C.c_int32), ("w_layout", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("relu", C.c_int32), ("out_f32", C.c_int32), ("w_rows", C.c_int32), ("w_layout", C.c_int32), ("w_split", C.c_int32), ("reserved", C.c_int32),
+        ("in_lo", C.c_void_p), ("in2_lo", C.c_void_p), ("out_lo", C.c_void_p),
     ]
 
 
@@ -231,20 +232,59 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+def split_f16(w):
+    """float64 tensor -> (hi, lo) float16 with hi = f16(w), lo = f16(w - hi): hi + lo keeps ~22 significant bits."""
+    hi = w.to(torch.float16)
+    lo = (w - hi.to(torch.float64)).to(torch.float16)
+    return hi, lo
+
+
+def pack_split_rows(w, nsub):
+    """1x1 weights float64 [rows][K] -> float16 [rows][K * nsub] in the order the "mixed" GEMM walks a 64-wide K block
+    (seg_gemm.hip, GemmArgs::nsub): nsub 2 = [hi | lo] (the activation block is used twice), nsub 3 = [hi | lo | hi]
+    (activation planes hi, hi, lo)."""
+    rows, k = w.shape
+    assert k % 64 == 0 and nsub in (2, 3)
+    hi, lo = split_f16(w)
+    parts = [hi.reshape(rows, k // 64, 1, 64), lo.reshape(rows, k // 64, 1, 64)]
+    if nsub == 3:
+        parts.append(parts[0])
+    return torch.cat(parts, dim=2).reshape(rows, k * nsub).contiguous()
+
+
+class Act(object):
+    """An activation [rows][ch]: one plane of the activation type, or ("mixed" precision) two float16 planes hi + lo of the
+    same shape."""
+    __slots__ = ("hi", "lo", "pool_key")
+
+    def __init__(self, hi, lo=None, pool_key=None):
+        self.hi, self.lo, self.pool_key = hi, lo, pool_key
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+
 class SegNet(object):
     """The compiled network for one input size and precision: device buffers, packed weights and the
     native plan.  ``forward(image_u8_cuda)`` runs it; ``labels`` / ``logits`` are views of its outputs."""
 
     ROW_PAD = 256        # GEMM tiles read whole 128/256-row tiles
 
-    def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8, fuse_dwpw=True):
+    def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8, fuse_dwpw=True, **mixed_opts):
         assert output_stride == 8, "the reference configuration is OS8 (base_cfg.py:106)"
-        assert precision in ("bf16", "f16", "f32")
+        assert precision in ("bf16", "f16", "f32", "mixed")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.H, self.W = int(height), int(width)
         self.precision = precision
-        self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[precision]
-        self.avl_dtype = {"bf16": _lib.AVL_BF16, "f16": _lib.AVL_F16, "f32": _lib.AVL_F32}[precision]
+        # "mixed": f16 MFMA with split operands where the error analysis (tools/precision_study.py, DESIGN.md section 4)
+        # says a single f16 rounding is too coarse: every weight is an f16 pair hi + lo, the residual trunk, the ASPP
+        # outputs and the whole decoder are stored as two f16 planes, and a GEMM runs 2 or 3 MFMA passes per K block.
+        self.mixed = precision == "mixed"
+        self.mixed_conv1_split = self.mixed and mixed_opts.get("conv1_split", True)     # conv1 / downsample read trunk hi + lo
+        self.mixed_conv2_split = self.mixed and mixed_opts.get("conv2_split", False)    # conv2 writes hi + lo, conv3 reads both
+        self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "mixed": torch.float16}[precision]
+        self.avl_dtype = {"bf16": _lib.AVL_BF16, "f16": _lib.AVL_F16, "f32": _lib.AVL_F32, "mixed": _lib.AVL_F16}[precision]
         self.half = precision != "f32"              # 16-bit activations: MFMA stem / grouped-conv kernels
         self.fuse_dwpw = bool(fuse_dwpw)            # ASPP branches: depthwise + pointwise as one kernel (16-bit types)
         self.num_classes = num_classes
@@ -265,18 +305,23 @@ class SegNet(object):
             pass
 
     # -------------------------------------------------------------------------------- buffers
-    def _act(self, rows, ch):
-        """activation buffer [rows padded][ch]"""
+    def _act(self, rows, ch, split=False):
+        """activation buffer [rows padded][ch] (split: two planes)"""
         prow = _round_up(rows, self.ROW_PAD)
-        key = (prow, ch)
+        key = (prow, ch, bool(split))
         if self._free.get(key):
             return self._free[key].pop()
-        t = torch.zeros((prow, ch), dtype=self.act_dtype, device=self.device)
+        if split:
+            t = torch.zeros((2, prow, ch), dtype=self.act_dtype, device=self.device)
+            a = Act(t[0], t[1], key)
+        else:
+            t = torch.zeros((prow, ch), dtype=self.act_dtype, device=self.device)
+            a = Act(t, None, key)
         self._keep.append(t)
-        return t
+        return a
 
-    def _release(self, t):
-        self._free.setdefault((t.shape[0], t.shape[1]), []).append(t)
+    def _release(self, a):
+        self._free.setdefault(a.pool_key, []).append(a)
 
     def _dev(self, t, dtype):
         t = t.to(dtype).contiguous().to(self.device)
@@ -295,17 +340,29 @@ class SegNet(object):
 
     @staticmethod
     def _view(t, col=0):
-        """(pointer to column `col` of a [rows][ld] buffer, ld, rows)"""
+        """(pointer to column `col` of a [rows][ld] buffer, ld, rows); t: Act (its high plane) or a tensor"""
+        t = t.hi if isinstance(t, Act) else t
         return t.data_ptr() + col * t.element_size(), t.shape[1], t.shape[0]
 
-    def _gemm(self, name, src, hw, cin, w, b, dst, dst_col=0, relu=True, res=None, out_f32=False, src_col=0, bias_dev=None):
-        """1x1 conv.  w float64 [cout][cin] (BN folded), b float64 [cout]."""
+    @staticmethod
+    def _lo(a, col=0):
+        """pointer to column `col` of an Act's low plane (0 = the activation is a single plane)"""
+        return 0 if (not isinstance(a, Act) or a.lo is None) else a.lo.data_ptr() + col * a.lo.element_size()
+
+    def _gemm(self, name, src, hw, cin, w, b, dst, dst_col=0, relu=True, res=None, out_f32=False, src_col=0, bias_dev=None,
+              read_lo=True):
+        """1x1 conv.  w float64 [cout][cin] (BN folded), b float64 [cout].  "mixed": weights become f16 pairs; the low
+        plane of `src` is read if it has one (unless read_lo = False), `res` and `dst` are used with all the planes they have."""
         h, wd = hw
         cout = w.shape[0]
         w_rows = _round_up(cout, 256)
         wp = torch.zeros((w_rows, cin), dtype=torch.float64)
         wp[:cout] = w.reshape(cout, cin)
-        wdev = self._dev(wp, self.act_dtype)
+        in_lo = self._lo(src, src_col) if (self.mixed and read_lo) else 0
+        if self.mixed:
+            wdev = self._dev(pack_split_rows(wp, 3 if in_lo else 2), torch.float16)
+        else:
+            wdev = self._dev(wp, self.act_dtype)
         if bias_dev is None:
             bp = torch.zeros(w_rows, dtype=torch.float64)
             bp[:cout] = b
@@ -318,6 +375,8 @@ class SegNet(object):
         if res is not None:
             rp, rld, _ = self._view(res)
             f.update(in2=rp, in2_ld=rld)
+        if self.mixed:
+            f.update(w_split=1, in_lo=in_lo, out_lo=self._lo(dst, dst_col), in2_lo=self._lo(res) if res is not None else 0)
         self._op(name, OP_GEMM, **f)
 
     def _dwpw(self, name, src, hw, cin, w_dw, b_dw, w_pw, b_pw, dst, dst_col, dilation, padding=None):
@@ -331,14 +390,16 @@ class SegNet(object):
         wp[:cout] = w_pw.reshape(cout, cin)
         bp = torch.zeros(w_rows, dtype=torch.float64)
         bp[:cout] = b_pw
-        wdev, bdev = self._dev(wp, self.act_dtype), self._dev(bp, torch.float32)
+        wdev = self._dev(pack_split_rows(wp, 2), torch.float16) if self.mixed else self._dev(wp, self.act_dtype)
+        bdev = self._dev(bp, torch.float32)
         params = torch.cat([pack_dw_pairs(w_dw, b_dw, self.act_dtype), dwpw_tile_order(oh, ow, dilation)]).to(self.device)
         self._keep.append(params)
         ip, ild, irows = self._view(src)
         op_, old, orows = self._view(dst, dst_col)
         self._op(name, OP_DWPW, in_=ip, in2=params.data_ptr(), out=op_, weight=wdev.data_ptr(), bias=bdev.data_ptr(), in_h=h, in_w=wd,
                  in_c=cin, in_ld=ild, in_rows=irows, out_h=oh, out_w=ow, out_c=cout, out_ld=old, out_rows=orows, relu=1, w_rows=w_rows,
-                 ksize=3, stride=1, pad=padding, dil=dilation, groups=cin)
+                 ksize=3, stride=1, pad=padding, dil=dilation, groups=cin, w_split=int(self.mixed),
+                 out_lo=self._lo(dst, dst_col) if self.mixed else 0)
 
     def _spatial(self, name, kind, src, in_hw, cin, dst, out_hw, cout, weight=None, bias=None, dst_col=0, **extra):
         ip, ild, irows = self._view(src)
@@ -349,6 +410,10 @@ class SegNet(object):
             f["weight"] = weight.data_ptr()
         if bias is not None:
             f["bias"] = bias.data_ptr()
+        if self.mixed and kind in (OP_BILINEAR, OP_DWCONV, OP_GCONV):
+            f["out_lo"] = self._lo(dst, dst_col)
+            if kind != OP_GCONV:
+                f["in_lo"] = self._lo(src)
         f.update(extra)
         self._op(name, kind, **f)
 
@@ -369,7 +434,7 @@ class SegNet(object):
             w_stem, stem_layout = self._dev(w.permute(2, 3, 1, 0).reshape(-1), torch.float32), 0   # [ky][kx][ci][co]
         b_stem = self._dev(b, torch.float32)
         stem = self._act(h2 * w2, 64)
-        self._op("backbone.conv1", OP_STEM, in_=self.image.data_ptr(), out=stem.data_ptr(), weight=w_stem.data_ptr(),
+        self._op("backbone.conv1", OP_STEM, in_=self.image.data_ptr(), out=stem.hi.data_ptr(), weight=w_stem.data_ptr(),
                  bias=b_stem.data_ptr(), in_h=H, in_w=W, in_c=3, in_ld=3, in_rows=H * W, out_h=h2, out_w=w2, out_c=64,
                  out_ld=64, out_rows=stem.shape[0], ksize=7, stride=2, pad=3, dil=1, groups=1, relu=1, w_layout=stem_layout)
         h4, w4 = (h2 + 2 - 3) // 2 + 1, (w2 + 2 - 3) // 2 + 1
@@ -397,37 +462,47 @@ class SegNet(object):
                 # conv1 1x1 + bn1 + relu
                 w, b = fold_bn(st, p + ".conv1.weight", p + ".bn1")
                 t1 = self._act(hw[0] * hw[1], width)
-                self._gemm(p + ".conv1", x, hw, cin, w, b, t1)
+                self._gemm(p + ".conv1", x, hw, cin, w, b, t1, read_lo=self.mixed_conv1_split)
                 # conv2 3x3 grouped + bn2 + relu
                 w, b = fold_bn(st, p + ".conv2.weight", p + ".bn2")
                 cg = width // GROUPS
                 if self.half and width % 64 == 0 and 32 % cg == 0:
-                    wg_d, layout = self._dev(pack_gconv_windows(w, GROUPS), self.act_dtype), 1
+                    if self.mixed:       # f16 pairs: 18 "taps" = 9 hi + 9 lo per window and n-tile
+                        nwin = width // 32
+                        whi, wlo = split_f16(w)
+                        packed = torch.cat([pack_gconv_windows(whi.to(torch.float64), GROUPS).reshape(nwin, 2, 9, 16, 32),
+                                            pack_gconv_windows(wlo.to(torch.float64), GROUPS).reshape(nwin, 2, 9, 16, 32)], dim=2)
+                        wg_d, layout = self._dev(packed.reshape(-1), torch.float16), 1
+                    else:
+                        wg_d, layout = self._dev(pack_gconv_windows(w, GROUPS), self.act_dtype), 1
                 else:
                     wg = w.reshape(GROUPS, cg, cg, 3, 3).permute(0, 3, 4, 2, 1).reshape(-1)   # [g][ky][kx][ci][co]
                     wg_d, layout = self._dev(wg, torch.float32), 0
                 bg_d = self._dev(b, torch.float32)
-                t2 = self._act(ohw[0] * ohw[1], width)
+                t2 = self._act(ohw[0] * ohw[1], width, split=self.mixed_conv2_split)
                 self._spatial(p + ".conv2", OP_GCONV, t1, hw, width, t2, ohw, width, wg_d, bg_d, ksize=3, stride=s, pad=d, dil=d,
-                              groups=GROUPS, relu=1, w_layout=layout)
+                              groups=GROUPS, relu=1, w_layout=layout, w_split=int(self.mixed))
                 self._release(t1)
                 # identity / downsample
                 if (p + ".downsample.0.weight") in st:
                     w, b = fold_bn(st, p + ".downsample.0.weight", p + ".downsample.1")
                     src = x
                     if s != 1:
-                        sub = self._act(ohw[0] * ohw[1], cin)
+                        keep_lo = self.mixed_conv1_split and x.lo is not None
+                        sub = self._act(ohw[0] * ohw[1], cin, split=keep_lo)
                         self._spatial(p + ".downsample.sub", OP_SUBSAMPLE, x, hw, cin, sub, ohw, cin, stride=s)
+                        if keep_lo:
+                            self._spatial(p + ".downsample.sub[lo]", OP_SUBSAMPLE, x.lo, hw, cin, sub.lo, ohw, cin, stride=s)
                         src = sub
-                    idn = self._act(ohw[0] * ohw[1], cout)
-                    self._gemm(p + ".downsample", src, ohw, cin, w, b, idn, relu=False)
+                    idn = self._act(ohw[0] * ohw[1], cout, split=self.mixed)
+                    self._gemm(p + ".downsample", src, ohw, cin, w, b, idn, relu=False, read_lo=self.mixed_conv1_split)
                     if s != 1:
                         self._release(sub)
                 else:
                     idn = x
                 # conv3 1x1 + bn3 + residual + relu
                 w, b = fold_bn(st, p + ".conv3.weight", p + ".bn3")
-                y = self._act(ohw[0] * ohw[1], cout)
+                y = self._act(ohw[0] * ohw[1], cout, split=self.mixed)
                 self._gemm(p + ".conv3", t2, ohw, width, w, b, y, relu=True, res=idn)
                 self._release(t2)
                 if idn is not x:
@@ -451,7 +526,7 @@ class SegNet(object):
         bch = [st["aspp.module_pyramid.0.conv.weight"].shape[0]] + [st["aspp.module_pyramid.%d.pointwise_cnn.conv.weight" % k].shape[0]
                                                                     for k in branches[1:]]
         ncat = sum(bch)
-        cat = self._act(M, ncat)
+        cat = self._act(M, ncat, split=self.mixed)
         w, b = fold_bn(st, "aspp.module_pyramid.0.conv.weight", "aspp.module_pyramid.0.bn")
         self._gemm("aspp.module_pyramid.0", feat, fhw, fc, w, b, cat, dst_col=0)
         col = bch[0]
@@ -464,7 +539,7 @@ class SegNet(object):
                 self._dwpw(p, feat, fhw, fc, w, b, w2, b2, cat, col, dil[k])
             else:
                 wd_, bd_ = self._dev(w.reshape(fc, 9).t().reshape(-1), torch.float32), self._dev(b, torch.float32)    # [tap][C]
-                t = self._act(M, fc)
+                t = self._act(M, fc, split=self.mixed)
                 self._spatial(p + ".depthwise_cnn", OP_DWCONV, feat, fhw, fc, t, fhw, fc, wd_, bd_, ksize=3, stride=1, pad=dil[k],
                               dil=dil[k], groups=fc, relu=1, in2=self.zero_page.data_ptr())
                 self._gemm(p + ".pointwise_cnn", t, fhw, fc, w2, b2, cat, dst_col=col)
@@ -492,7 +567,7 @@ class SegNet(object):
         self._op("aspp.conv[pool slice]", OP_GEMV, dtype=_lib.AVL_F32, in_=pool_vec.data_ptr(), out=proj_bias.data_ptr(), weight=wpd.data_ptr(),
                  bias=bpd.data_ptr(), in_h=1, in_w=1, in_c=npool, in_ld=npool, in_rows=1, out_h=1, out_w=1, out_c=aspp_out,
                  out_ld=aspp_out, out_rows=1, relu=0)
-        aspp = self._act(M, aspp_out)
+        aspp = self._act(M, aspp_out, split=self.mixed)
         self._gemm("aspp.conv", cat, fhw, ncat, wp_[:, :ncat], None, aspp, bias_dev=proj_bias)       # dropout = identity (eval)
         self._release(cat)
         self._release(feat)
@@ -501,7 +576,7 @@ class SegNet(object):
         w, b = fold_bn(st, "decoder.low_level_conv.conv.weight", "decoder.low_level_conv.bn")
         low_out = w.shape[0]
         Ml = low_hw[0] * low_hw[1]
-        cat2 = self._act(Ml, aspp_out + low_out)
+        cat2 = self._act(Ml, aspp_out + low_out, split=self.mixed)
         self._gemm("decoder.low_level_conv", low, low_hw, low_c, w, b, cat2, dst_col=aspp_out)
         self._spatial("decoder.interpolate", OP_BILINEAR, aspp, fhw, aspp_out, cat2, low_hw, aspp_out)
         self._release(aspp)
@@ -513,13 +588,16 @@ class SegNet(object):
             ohw = (hw[0] - 2, hw[1] - 2)                                # padding 0 (decoder.py:33-36 default)
             w, b = fold_bn(st, p + ".depthwise_cnn.conv.weight", p + ".depthwise_cnn.bn")
             w2, b2 = fold_bn(st, p + ".pointwise_cnn.conv.weight", p + ".pointwise_cnn.bn")
-            y = self._act(ohw[0] * ohw[1], w2.shape[0])
-            if self.half and self.fuse_dwpw and cin % 64 == 0 and cin <= 2048:
+            y = self._act(ohw[0] * ohw[1], w2.shape[0], split=self.mixed)
+            # "mixed": the decoder keeps every activation as hi + lo and its depthwise weights in fp32 (the logits are most
+            # sensitive to roundings here: tools/precision_study.py), so the two kernels stay separate (split depthwise
+            # kernel -> three-pass GEMM)
+            if self.half and self.fuse_dwpw and cin % 64 == 0 and cin <= 2048 and not self.mixed:
                 self._dwpw(p, x, hw, cin, w, b, w2, b2, y, 0, 1, padding=0)
                 self._release(x)
             else:
                 wd_, bd_ = self._dev(w.reshape(cin, 9).t().reshape(-1), torch.float32), self._dev(b, torch.float32)
-                t = self._act(ohw[0] * ohw[1], cin)
+                t = self._act(ohw[0] * ohw[1], cin, split=self.mixed)
                 self._spatial(p + ".depthwise_cnn", OP_DWCONV, x, hw, cin, t, ohw, cin, wd_, bd_, ksize=3, stride=1, pad=0, dil=1, groups=cin, relu=1,
                               in2=self.zero_page.data_ptr())
                 self._release(x)
@@ -535,7 +613,7 @@ class SegNet(object):
         self.logits_buf = torch.zeros((_round_up(Mo, self.ROW_PAD), self.num_classes), dtype=torch.float32, device=dev)
         self.labels_buf = torch.zeros(_round_up(Mo, self.ROW_PAD), dtype=torch.uint8, device=dev)
         self._keep += [self.logits_buf, self.labels_buf]
-        self._gemm(p, x, hw, cin, w, b, self.logits_buf, relu=False, out_f32=True)
+        self._gemm(p, x, hw, cin, w, b, Act(self.logits_buf), relu=False, out_f32=True)
         self._op("argmax", OP_ARGMAX, dtype=_lib.AVL_F32, in_=self.logits_buf.data_ptr(), out=self.labels_buf.data_ptr(), in_h=hw[0], in_w=hw[1],
                  in_c=self.num_classes, in_ld=self.num_classes, in_rows=self.logits_buf.shape[0], out_h=hw[0], out_w=hw[1], out_c=1,
                  out_ld=1, out_rows=self.labels_buf.shape[0])
