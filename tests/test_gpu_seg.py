@@ -3,10 +3,11 @@
 weights (no trained weights exist offline; BN statistics are randomised so folding is exercised).
 
 Tolerances (north_star: logits within 1e-3 relative):
-  * MODEL.PRECISION = "f32"  (fp32-input MFMA): max|dlogit| / max|logit| <= 1e-3   -- the parity bar
-  * MODEL.PRECISION = "bf16" (the bench path):  bf16 keeps 8 significand bits per activation, so after
-    ~55 layers the logits carry a few 1e-2 of relative error; asserted <= 6e-2 and reported, with
-    arg-max agreement asserted >= 95 % (measured values are printed)."""
+  * MODEL.PRECISION = "mixed" (the default and the bench path; tests/test_gpu_mixed.py) and "f32" (fp32-input MFMA):
+    max|dlogit| / max|logit| <= 1e-3   -- the parity bar
+  * MODEL.PRECISION = "f16" / "bf16" (one 16-bit rounding per tensor, the fastest modes): 11 / 8 significand bits per
+    activation, so after ~55 layers the logits carry 2e-3 / 1-2e-2 of relative error; asserted <= 4e-3 / 4e-2 with
+    arg-max agreement >= 99 % / 95 % (measured values are printed)."""
 import os
 
 import numpy as np
@@ -57,7 +58,7 @@ def test_f32_logits_within_1e3_of_oracle(state, hw, cuda_device):
 def test_bf16_logits_close_to_oracle(state, hw, cuda_device):
     rel, agree = _compare(state, "bf16", hw[0], hw[1], cuda_device)
     print("bf16 %dx%d: max rel err %.3e, argmax agreement %.5f" % (hw[0], hw[1], rel, agree))
-    assert rel <= 6e-2
+    assert rel <= 4e-2
     assert agree >= 0.95
 
 
@@ -66,7 +67,7 @@ def test_f16_logits_close_to_oracle(state, hw, cuda_device):
     """MODEL.PRECISION = "f16": same MFMA rate as bf16, 3 more significand bits per activation."""
     rel, agree = _compare(state, "f16", hw[0], hw[1], cuda_device)
     print("f16 %dx%d: max rel err %.3e, argmax agreement %.5f" % (hw[0], hw[1], rel, agree))
-    assert rel <= 8e-3
+    assert rel <= 4e-3
     assert agree >= 0.99
 
 
@@ -121,11 +122,12 @@ def test_node_callback_and_fused_mapping(state, cuda_device):
     assert torch.equal(a.map_dev, b.map_dev) and float(a.map_dev.abs().sum()) > 0
 
 
-def test_hipgraph_replay_is_identical(state, cuda_device):
+@pytest.mark.parametrize("precision", ["bf16", "mixed"])
+def test_hipgraph_replay_is_identical(state, precision, cuda_device):
     """avl_seg_plan_capture: the captured plan replays to bit-identical logits, frame after frame."""
     import torch
     from vision_semantic_segmentation_amd.network import SegNet
-    net = SegNet(state, 96, 128, precision="bf16", device=cuda_device)
+    net = SegNet(state, 96, 128, precision=precision, device=cuda_device)
     rng = np.random.default_rng(5)
     a = torch.from_numpy(rng.integers(0, 256, size=(96, 128, 3), dtype=np.uint8)).to(cuda_device)
     b = torch.from_numpy(rng.integers(0, 256, size=(96, 128, 3), dtype=np.uint8)).to(cuda_device)
@@ -139,12 +141,13 @@ def test_hipgraph_replay_is_identical(state, cuda_device):
         assert torch.equal(net.logits, ref)
 
 
-def test_full_size_frame_repeats_under_graph_replay(state, cuda_device):
+@pytest.mark.parametrize("precision", ["bf16", "mixed"])
+def test_full_size_frame_repeats_under_graph_replay(state, precision, cuda_device):
     """1080 x 1920 (more 128-pixel tiles than CUs in the decoder): eager run and 30 hipGraph replays give the same logits
     bit for bit.  (A hand-scheduled version of the fused depthwise+pointwise kernel failed exactly this, rarely.)"""
     import torch
     from vision_semantic_segmentation_amd.network import SegNet
-    net = SegNet(state, 1080, 1920, precision="bf16", device=cuda_device)
+    net = SegNet(state, 1080, 1920, precision=precision, device=cuda_device)
     img = torch.from_numpy(np.random.default_rng(12).integers(0, 256, size=(1080, 1920, 3), dtype=np.uint8)).to(cuda_device)
     net.forward(img)
     torch.cuda.synchronize()
@@ -163,7 +166,7 @@ def test_config_a_640x480_against_oracle(state, cuda_device):
     assert rel <= 1e-3 and agree >= 0.999
     rel, agree = _compare(state, "bf16", 480, 640, cuda_device, seed=3)
     print("bf16 480x640: max rel err %.3e, argmax agreement %.5f" % (rel, agree))
-    assert rel <= 6e-2 and agree >= 0.95
+    assert rel <= 4e-2 and agree >= 0.95
 
 
 def test_real_camera_size_1440x1920(state, cuda_device):

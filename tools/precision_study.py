@@ -205,6 +205,26 @@ def main():
                 c5["layer%d.%d.conv2:a" % (li, b)] = "f32"
         report("C5: C3 + l1/l2 conv2 out split", Policy("f16", **c5))
         report("C6: C2 + C3", Policy("f16", **dict(c3, **{"layer3:ta": "f32", "layer4:ta": "f32"})))
+    if sel == "w":
+        d = {":w": X, ":t": "f32", ":ta": "f32", "stem": "f16", "dec": "f32", "dec:w": X,
+             "aspp.b0:a": "f32", "aspp.proj:a": "f32"}
+        for i in (1, 2, 3):
+            d["aspp.b%d.dw" % i] = "f16"
+            d["aspp.b%d.pw:a" % i] = "f32"
+        report("built (V9)", Policy("f16", **d))
+        def blocks(layers, conv, dd):
+            for li, nb in layers:
+                for b in range(nb):
+                    dd["layer%d.%d.%s:a" % (li, b, conv)] = "f32"
+            return dd
+        L34, L12 = ((3, 6), (4, 3)), ((1, 3), (2, 4))
+        report("+ l3/4 conv1 out split", Policy("f16", **blocks(L34, "conv1", dict(d))))
+        report("+ l1-4 conv1 out split", Policy("f16", **blocks(L34 + L12, "conv1", dict(d))))
+        report("+ l1/2 conv1+conv2 out split", Policy("f16", **blocks(L12, "conv2", blocks(L12, "conv1", dict(d)))))
+        report("+ l1-4 conv1 split, l1/2 conv2 split", Policy("f16", **blocks(L12, "conv2", blocks(L34 + L12, "conv1", dict(d)))))
+        report("+ l1-4 conv1 split, l1/2 conv2 split, stem w x2", Policy("f16", **dict(blocks(L12, "conv2", blocks(L34 + L12, "conv1", dict(d))), **{"stem:w": X})))
+        report("+ all conv1, conv2 split", Policy("f16", **blocks(L34 + L12, "conv2", blocks(L34 + L12, "conv1", dict(d)))))
+        report("+ all conv1, conv2 split, stem exact, aspp dw exact", Policy("f16", **dict(blocks(L34 + L12, "conv2", blocks(L34 + L12, "conv1", dict(d))), **{"stem": "f32", "aspp.b1.dw": "f32", "aspp.b2.dw": "f32", "aspp.b3.dw": "f32"})))
     print("den (max|logit|) = %.3f" % den)
 
 

@@ -158,10 +158,12 @@ struct DwGeom {
     int units, upb;        // (comb, band) units in total / per workgroup
 };
 
-template <typename T>
+// SPLIT ("mixed" precision, f16): input and output are two planes hi + lo (in_lo / out_lo, same offsets); the taps are
+// summed to fp32 (exact) and go through the fp32 FMA chain with the fp32 weights, nothing is rounded away at the output.
+template <typename T, bool SPLIT = false>
 __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, const float* __restrict__ w,
                                                     const float* __restrict__ bias, T* __restrict__ out, const T* __restrict__ zero,
-                                                    DwGeom g) {
+                                                    DwGeom g, const T* __restrict__ in_lo = nullptr, T* __restrict__ out_lo = nullptr) {
     const int cgrp = blockIdx.x % g.cgroups, ub = blockIdx.x / g.cgroups;
     const int chunk = threadIdx.x % g.nchunk, cl = threadIdx.x / g.nchunk;
     if (cl >= g.cl) return;
@@ -180,12 +182,12 @@ __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, c
         const float4 b1 = *reinterpret_cast<const float4*>(bias + c8 * 8 + 4);
         bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
     }
-    constexpr int NR = sizeof(T) == 2 ? 1 : 2;
+    constexpr int NR = (sizeof(T) == 2 && !SPLIT) ? 1 : 2;        // 16-byte registers per tap: f32 = 8 floats; split = hi chunk, lo chunk
     // 16-bit types: taps are paired (0,1)(2,3)(4,5)(6,7)(8,-) and each channel's two taps go through one
     // v_dot2c_f32_{bf16,f16} (exact products, fp32 accumulate) -- 1 vector op per MAC instead of convert + FMA.
     // The folded weights are rounded to the activation type for it, like every GEMM weight of the network.
     uint32_t wp[5][8];
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2 && !SPLIT) {
 #pragma unroll
         for (int pr = 0; pr < 5; ++pr)
 #pragma unroll
@@ -224,7 +226,10 @@ __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, c
                 for (int k = 0; k < 3; ++k) {
                     const uint4* src = reinterpret_cast<const uint4*>((rok && cok[k]) ? rowp + coff[k] : zero);
                     dst[k][0] = src[0];
-                    if constexpr (NR == 2) dst[k][1] = src[1];
+                    if constexpr (SPLIT) {
+                        const uint4* srl = reinterpret_cast<const uint4*>((rok && cok[k]) ? in_lo + (long long)iy * g.W * g.in_ld + coff[k] : zero);
+                        dst[k][1] = srl[0];
+                    } else if constexpr (NR == 2) dst[k][1] = src[1];
                 }
             };
             const int oy0 = ry + gy0 * g.dil;
@@ -248,7 +253,16 @@ __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, c
             float acc[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = bs[i];
-            if constexpr (sizeof(T) == 2) {
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    float vh[8], vl[8];
+                    Vec8<T>::load(reinterpret_cast<const T*>(&raw[t][0]), vh);
+                    Vec8<T>::load(reinterpret_cast<const T*>(&raw[t][1]), vl);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(vh[i] + vl[i], wt[t][i], acc[i]);
+                }
+            } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
                 for (int pr = 0; pr < 5; ++pr) {
                     const uint32_t* ra = reinterpret_cast<const uint32_t*>(&raw[2 * pr][0]);
@@ -276,6 +290,11 @@ __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, c
                 for (int i = 0; i < 8; ++i) acc[i] = fmaxf(acc[i], 0.f);
             }
             Vec8<T>::store(out + ((long long)oy * g.OW + ox) * g.out_ld + c8 * 8, acc);
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] -= to_f32(from_f32<T>(acc[i]));
+                Vec8<T>::store(out_lo + ((long long)oy * g.OW + ox) * g.out_ld + c8 * 8, acc);
+            }
             }
         }
     }
@@ -564,7 +583,7 @@ int launch_typed(const avl_seg_op& op, hipStream_t s) {
             break;
         }
         case AVL_OP_DWCONV: {
-            if (op.in_lo || op.out_lo) {
+            if ((op.in_lo == nullptr) != (op.out_lo == nullptr)) {      // one side split only: the simple kernel
                 hipLaunchKernelGGL(k_dwconv_split<T>, dim3(blocks_for((long long)op.out_h * op.out_w * (op.in_c / 8))), dim3(kThreads), 0, s,
                                    in, static_cast<const T*>(op.in_lo), w, op.bias, out, static_cast<T*>(op.out_lo), op.in_h, op.in_w,
                                    op.in_c, op.in_ld, op.out_h, op.out_w, op.out_ld, op.pad, op.dil, op.relu);
@@ -599,8 +618,15 @@ int launch_typed(const avl_seg_op& op, hipStream_t s) {
             const int target = 32 * g.cl, unit_px = g.band_h * g.band_w;
             g.upb = (op.dil == 1 || unit_px >= target) ? 1 : (target + unit_px - 1) / unit_px;
             const unsigned nblk = (unsigned)((g.units + g.upb - 1) / g.upb) * g.cgroups;
-            hipLaunchKernelGGL(k_dwconv<T>, dim3(nblk), dim3(kThreads), 0, s, in, w, op.bias, out,
-                               static_cast<const T*>(op.in2), g);
+            if constexpr (sizeof(T) == 2) {
+                if (op.in_lo && op.out_lo) {
+                    hipLaunchKernelGGL((k_dwconv<T, true>), dim3(nblk), dim3(kThreads), 0, s, in, w, op.bias, out,
+                                       static_cast<const T*>(op.in2), g, static_cast<const T*>(op.in_lo), static_cast<T*>(op.out_lo));
+                    break;
+                }
+            }
+            hipLaunchKernelGGL((k_dwconv<T, false>), dim3(nblk), dim3(kThreads), 0, s, in, w, op.bias, out,
+                               static_cast<const T*>(op.in2), g, static_cast<const T*>(nullptr), static_cast<T*>(nullptr));
             break;
         }
         case AVL_OP_BILINEAR:

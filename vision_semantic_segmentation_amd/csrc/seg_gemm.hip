@@ -242,12 +242,16 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm(GemmArgs p) {
 // ring advance independently: a sub-step always brings a weight tile, an activation tile only when it changes
 // (sub_needs_a), so W hi/lo cost 1.5x the L2->LDS bytes of the plain GEMM for 2x the MFMAs.
 // IO: the epilogue may read a split residual (R + R_lo) and write a split result (C + C_lo), both optional at run time.
-template <typename H, int WM, int WN, int MI, int STAGES, int PROBE = 0, int NSUB = 1, int IO = 0>
+// STAGES = weight tiles in the ring (the producer runs STAGES - 1 sub-steps ahead); AST = activation tiles in the ring:
+// = STAGES for the plain GEMM; 2 is enough for NSUB = 2 at any depth because an activation tile lives for two sub-steps
+// (256 x 256 tile: 2 x 32 KB + 3 x 32 KB = the whole 160 KB of LDS, two sub-steps of DMA in flight instead of one).
+template <typename H, int WM, int WN, int MI, int STAGES, int PROBE = 0, int NSUB = 1, int IO = 0, int AST = STAGES>
 __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtiles) {
     typedef typename Half16<H>::v8 v8;
     constexpr int NW = WM * WN, BM = WM * MI * 16, BN = WN * 64;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
-    constexpr int W_REGION = STAGES * A_BYTES;                 // LDS: [STAGES activation tiles][STAGES weight tiles]
+    constexpr int W_REGION = AST * A_BYTES;                    // LDS: [AST activation tiles][STAGES weight tiles]
+    static_assert(AST == STAGES || (NSUB == 2 && AST == 2), "activation ring too short for this pass pattern");
     constexpr int A_INSTR = BM / 8 / NW, W_INSTR = BN / 8 / NW;
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
@@ -290,7 +294,7 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtile
     auto issue_part = [&](int h, int np, int jj) {
         const bool na = sub_needs_a<NSUB>(jj);
         if (na) {
-            const unsigned abase = lds_base + (issued_a % STAGES) * A_BYTES + wave * 1024;
+            const unsigned abase = lds_base + (issued_a % AST) * A_BYTES + wave * 1024;
             const long long aoff = (long long)pk * 128 + ((NSUB == 3 && jj == 2) ? p.a_lo_delta : 0);
 #pragma unroll
             for (int i = 0; i < A_INSTR; ++i)
@@ -362,7 +366,7 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtile
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const bool feed = pt < total;                  // sub-step g+STAGES-1 -> the slots consumed in step g-1
-            const char* abase = lds + (ca % STAGES) * A_BYTES;
+            const char* abase = lds + (ca % AST) * A_BYTES;
             const char* wbase = lds + (g % STAGES) * W_BYTES;
             if (PROBE == 1) { if (feed) issue_part(0, 1, jn); continue; }      // DMA only
             auto rd_w = [&](int kk, int nj) { return *reinterpret_cast<const v8*>(wbase + w_off[nj] + (((kk * 4 + kq) ^ w_key[nj]) << 4)); };
@@ -493,12 +497,12 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtile
     }
 }
 
-template <typename H, int WM, int WN, int MI, int STAGES, int NSUB = 1, int IO = 0>
+template <typename H, int WM, int WN, int MI, int STAGES, int NSUB = 1, int IO = 0, int AST = STAGES>
 int launch_ring(const GemmArgs& a0, int M, hipStream_t s) {
-    constexpr int BM = WM * MI * 16, BN = WN * 64, LDS = STAGES * (BM + BN) * 128;
+    constexpr int BM = WM * MI * 16, BN = WN * 64, LDS = (AST * BM + STAGES * BN) * 128;
     static_assert(LDS <= 160 * 1024, "ring does not fit LDS");
     // set on every launch: the attribute is per device and this may be called from several threads / for several devices
-    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<H, WM, WN, MI, STAGES, 0, NSUB, IO>),
+    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<H, WM, WN, MI, STAGES, 0, NSUB, IO, AST>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     GemmArgs a = a0;
     a.ntiles = (a.N + BN - 1) / BN;
@@ -510,7 +514,7 @@ int launch_ring(const GemmArgs& a0, int M, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<H, WM, WN, MI, STAGES, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         hipLaunchKernelGGL((k_gemm_ring<H, WM, WN, MI, STAGES, 1>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
     } else
-        hipLaunchKernelGGL((k_gemm_ring<H, WM, WN, MI, STAGES, 0, NSUB, IO>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
+        hipLaunchKernelGGL((k_gemm_ring<H, WM, WN, MI, STAGES, 0, NSUB, IO, AST>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
@@ -589,7 +593,8 @@ int launch_gemm(const avl_seg_op& op, hipStream_t s) {
         int v = op.w_layout;
         if (v == 0) v = (can256 && ((a.M + 255) / 256) * (a.N / 256) >= 192) ? 3 : 2;
         if (a.nsub == 2) {
-            if (v == 3 && can256) return launch_ring<f16, 2, 4, 8, 2, 2, 1>(a, a.M, s);
+            static const int deep = getenv("AVL_GEMM_DEEP") ? atoi(getenv("AVL_GEMM_DEEP")) : 1;      // A/B: 0 = 2 + 2 tiles, one sub-step ahead
+            if (v == 3 && can256) return deep ? launch_ring<f16, 2, 4, 8, 3, 2, 1, 2>(a, a.M, s) : launch_ring<f16, 2, 4, 8, 2, 2, 1>(a, a.M, s);
             return launch_ring<f16, 4, 2, 4, 3, 2, 1>(a, a.M, s);
         }
         if (a.nsub == 3) {

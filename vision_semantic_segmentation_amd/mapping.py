@@ -487,13 +487,14 @@ class SemanticMapping(object):
         return map
 
     # ------------------------------------------------------------------ multi-GPU: shared global grid
-    def global_map(self, group=None, dst=None):
+    def global_map(self, group=None, dst=None, exchange_dtype=None):
         """Sum of every rank's private grid: each rank maps its own camera stream into its
         own grid; since a frame's contribution never depends on the grid's content, the shared grid
         is the element-wise sum.  all_reduce (or reduce to ``dst``) over RCCL on a copy, so the private
-        grid keeps accumulating.  Returns the CUDA tensor (valid on every rank, or on dst only)."""
+        grid keeps accumulating.  Returns the CUDA tensor (valid on every rank, or on dst only).
+        ``exchange_dtype=torch.float32`` halves the payload (see distributed.reduce_grids)."""
         from .distributed import reduce_grids
-        return reduce_grids(self.grid.map, group=group, dst=dst)
+        return reduce_grids(self.grid.map, group=group, dst=dst, exchange_dtype=exchange_dtype)
 
     def save_inputs(self, path=None):
         """The reference dumps input_list with hickle (mapping.py:324-326); hickle is optional here,

@@ -28,7 +28,7 @@ class SemanticSegmentation(object):
             raise NotImplementedError("only the reference configuration (DeepLabv3+, resnext50_32x4d, OS8) is built")
         self.cfg = cfg
         self.num_classes = cfg.DATASET.NUM_CLASSES
-        self.precision = getattr(cfg.MODEL, "PRECISION", "bf16")
+        self.precision = getattr(cfg.MODEL, "PRECISION", "mixed")
         kw = dict(num_classes=self.num_classes, in_channels=cfg.DATASET.IN_CHANNELS, aspp_out=cfg.MODEL.ASPP.OUT_CHANNELS,
                   atrous_channels=tuple(cfg.MODEL.ASPP.ATROUS_CHANNELS), low_level_out=cfg.MODEL.DECODER.LOW_LEVEL_OUT_CHANNELS,
                   refine_channels=tuple(cfg.MODEL.DECODER.REFINE_CHANNELS))
@@ -45,7 +45,8 @@ class SemanticSegmentation(object):
         """The compiled plan for an h x w input (built on first use, kept per size)."""
         key = (int(h), int(w))
         if key not in self._nets:
-            net = SegNet(self.state, key[0], key[1], precision=self.precision, device=self.device, num_classes=self.num_classes)
+            net = SegNet(self.state, key[0], key[1], precision=self.precision, device=self.device, num_classes=self.num_classes,
+                         conv2_split=bool(getattr(self.cfg.MODEL, "MIXED_CONV2_SPLIT", False)))
             if getattr(self.cfg.MODEL, "HIP_GRAPH", True):
                 net.capture_graph()
             self._nets[key] = net
