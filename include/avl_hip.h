@@ -149,6 +149,15 @@ int avl_preprocess_image(const uint8_t* bgr, int h, int w, const double* K_host,
 int avl_pack_semantic_cloud(const double* pcd, const uint8_t* label, int64_t ld, int m_host, const int32_t* m_dev,
                             void* out_records, void* stream);
 
+/* pcd_callback (src/mapping.py:172-183) without its per-point Python loop: a sensor_msgs/PointCloud2 payload
+ * (`data`, n_points records of point_step bytes, FLOAT32 fields x / y / z / intensity at the given byte offsets, all
+ * multiples of 4) -> out_xyzi float32[n_points][4], the layout avl_fused_frame reads.  read_points(skip_nans=True)
+ * (:179) drops every point with a NaN in ANY of the four fields; here such a point keeps its slot but gets x = NaN, which
+ * the projection kernels reject, so frame results are identical and no compaction pass is needed.
+ * n_valid (device int32, or NULL) receives the number of points read_points would have yielded. */
+int avl_unpack_pointcloud2(const uint8_t* data, int64_t n_points, int point_step, int off_x, int off_y, int off_z, int off_i,
+                           float* out_xyzi, int32_t* n_valid, void* stream);
+
 /* ---- end-of-run rendering (src/renderer.py; called at src/mapping.py:332-334) ------------
  * map [Hm][Wm][C] of map_dtype (AVL_F64 | AVL_F32); colors_host uint8[C][3]; out uint8[Hm][Wm][3]. */
 /* render_bev_map (renderer.py:32-59): colour of the arg-max channel, black where the channel sum is 0 */

@@ -16,6 +16,8 @@ What is imported from the reference:
     CPU forward at small sizes with seeded weights and randomised BN statistics.
   * test/test_semantic_mapping.py -> convert_labels (:6-19) and Test.iou (:127-161), compiled from their own
     line ranges (the module as a whole is a SyntaxError) -- `python oracle/gen_golden.py eval`.
+  * mapillary_visualization.py (get_labels, apply_color_map), src/data/confusion_matrix.py and the default values of
+    src/config/base_cfg.py -> `python oracle/gen_golden.py misc` (see gen_misc).
 The backbone (torchvision) cannot be imported here; it has no fixture (parity unpinned).
 
 The fixtures hold inputs and expected outputs only -- no reference source text.
@@ -303,8 +305,107 @@ def gen_eval():
     print("wrote eval.npz (%d arrays)" % len(out))
 
 
+def gen_misc():
+    """Reference-held pieces that import with numpy / json only ("pin what the reference itself can pin"):
+      * deeplab_v3_plus/data/utils/mapillary_visualization.py: get_labels (:9-18) on config/config_19.json and
+        apply_color_map (:70-89) on 2-D and batched label arrays (ids 0..18 plus out-of-table ids) -> misc.npz
+      * src/data/confusion_matrix.py: ConfusionMatrix.get_submatrix (:25-48) and helpers on a seeded matrix -> misc.npz
+      * src/config/base_cfg.py (+ network/deeplab_v3_plus/config/{demo,deeplab_v3_plus}.py): the default values, through a
+        dict-backed CfgNode stand-in for yacs (absent here) -> base_cfg.json
+    `python oracle/gen_golden.py misc`."""
+    import importlib.util
+    import json
+    import tempfile
+    out = {}
+
+    # ---- mapillary_visualization: its dataset import (PIL, torch datasets) is not needed by the two functions
+    _stub("deeplab_v3_plus")
+    _stub("deeplab_v3_plus.data")
+    _stub("deeplab_v3_plus.data.dataset")
+    _stub("deeplab_v3_plus.data.dataset.mapillary", MapillaryVistas=object)
+    spec = importlib.util.spec_from_file_location(
+        "ref_mapillary_visualization", os.path.join(REF, "src", "network", "deeplab_v3_plus", "data", "utils", "mapillary_visualization.py"))
+    mv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mv)
+    labels = mv.get_labels(os.path.join(REF, "config", "config_19.json"))
+    out["palette"] = np.array([l["color"] for l in labels], dtype=np.int64)
+    out["palette_names"] = np.array([l["name"] for l in labels])
+    rng = np.random.default_rng(31)
+    lab2 = rng.integers(0, 19, size=(37, 53)).astype(np.int64)
+    lab2[0, :6] = [19, 20, 255, 300, -1, 18]                  # ids outside the table stay black
+    lab3 = rng.integers(0, 19, size=(2, 11, 13)).astype(np.uint8)
+    out["labels_2d"], out["colors_2d"] = lab2, mv.apply_color_map(lab2, labels)
+    out["labels_3d"], out["colors_3d"] = lab3, mv.apply_color_map(lab3, labels)
+
+    # ---- ConfusionMatrix
+    spec = importlib.util.spec_from_file_location("ref_confusion_matrix", os.path.join(REF, "src", "data", "confusion_matrix.py"))
+    cmod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cmod)
+    mtx = rng.integers(1, 5000, size=(19, 19)).astype(np.float64)
+    mtx[np.arange(19), np.arange(19)] += 40000.0
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "cfn_mtx.npy")
+        np.save(path, mtx)
+        cm = cmod.ConfusionMatrix(path)
+    idx = [2, 1, 8, 10, 3]                                   # base_cfg.py:47 LABELS
+    out["cfn_mtx"] = mtx
+    out["cfn_indices"] = np.array(idx)
+    out["cfn_sub"] = cm.get_submatrix(idx)
+    out["cfn_sub_prob"] = cm.get_submatrix(idx, to_probability=True)
+    out["cfn_sub_log"] = cm.get_submatrix(idx, to_probability=True, use_log=True)     # what mapping.py:128-129 asks for
+    out["cfn_sub_log_without_prob"] = cm.get_submatrix(idx, use_log=True)             # use_log alone is ignored
+    out["cfn_sub_perm"] = cm.get_submatrix([18, 0, 7], True, True)
+    out["cfn_len"] = np.int64(len(cm))
+    out["cfn_row3"] = cm[3]
+    assert cm.get_submatrix([]) == []
+    errs = []
+    for bad in ([0, 19], [-1, 2], list(range(19)) + [0]):
+        try:
+            cm.get_submatrix(bad)
+            errs.append("")
+        except ValueError as e:
+            errs.append(str(e.args[0]))
+    out["cfn_errors"] = np.array(errs)
+    np.savez_compressed(os.path.join(OUT, "misc.npz"), **out)
+    print("wrote misc.npz (%d arrays)" % len(out))
+
+    # ---- base_cfg defaults
+    class CN(dict):
+        """the part of yacs.config.CfgNode the three config files use: attribute access and clone()"""
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+        def clone(self):
+            import copy
+            return copy.deepcopy(self)
+
+    for name in [n for n in sys.modules if n == "src" or n.startswith("src.") or n.startswith("yacs")]:
+        del sys.modules[name]
+    _stub("yacs")
+    _stub("yacs.config", CfgNode=CN)
+    sys.path.insert(0, REF)
+    import importlib
+    base = importlib.import_module("src.config.base_cfg")
+    cfg = base.get_cfg_defaults()
+
+    def plain(node):
+        return {k: plain(v) for k, v in node.items()} if isinstance(node, dict) else (list(node) if isinstance(node, tuple) else node)
+    with open(os.path.join(OUT, "base_cfg.json"), "w") as f:
+        json.dump(plain(cfg), f, indent=1, sort_keys=True)
+    print("wrote base_cfg.json:", sorted(cfg.keys()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "misc":
+        gen_misc()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "eval":
         gen_eval()
         sys.exit(0)
@@ -316,3 +417,4 @@ if __name__ == "__main__":
     gen_network()
     gen_render()
     gen_eval()
+    gen_misc()

@@ -258,3 +258,50 @@ def test_semantic_point_cloud_records(cuda_device):
         assert data[16 * k:16 * k + 16] == expect
     host = create_point_cloud(xyz, rgb, frame_id="velodyne")
     assert host["point_step"] == 16 and host["width"] == m and host["data"] == data
+
+
+def test_pointcloud2_unpack_on_device(cuda_device):
+    """avl_unpack_pointcloud2 (pcd_callback, mapping.py:172-183): a hand-packed velodyne-style payload (32-byte records, padding
+    bytes that are not zero, NaN in each of the four fields) unpacked on the GPU == the host unpack, slot for slot; and a
+    frame mapped from the device points == the frame mapped from the host-unpacked float64 [4,M] array, bit for bit."""
+    import torch
+    from test_fixtures_misc import _pointcloud2
+    from oracle import mapping_oracle as mo
+    from vision_semantic_segmentation_amd import synthetic as syn
+    from vision_semantic_segmentation_amd.camera import camera_setup_1
+    from vision_semantic_segmentation_amd.mapping import unpack_pointcloud2
+    rng = np.random.default_rng(17)
+    H, W = 480, 640
+    cam = camera_setup_1().scaled(W / 1920.0, H / 1440.0)
+    cloud = syn.make_cloud(rng, 30000, cam.K, cam.R, cam.t, W, H).astype(np.float32)       # has NaN / inf / far points
+    cloud[3, 5::97] = np.nan                                                                 # NaN intensity only: read_points skips those too
+    cloud[1, 11::101] = np.nan
+    pts = [tuple(float(v) for v in cloud[:, k]) for k in range(cloud.shape[1])]
+    msg = _pointcloud2(pts)
+    host = unpack_pointcloud2(msg)                                                           # float64 [4, M]
+    boundary = syn.centred_boundary(mo.PCD_ORIGIN_OFFSET[:2], 100.0)
+    a = make_sm(boundary, 0.2, syn.log_confusion(5), True, cuda_device)
+    dev_pts, count = a.unpack_pointcloud2_device(msg)
+    assert tuple(dev_pts.shape) == (30000, 4) and dev_pts.dtype == torch.float32
+    got = dev_pts.cpu().numpy()
+    bad = np.isnan(cloud).any(axis=0)
+    assert int(count.item()) == int((~bad).sum()) == host.shape[1]
+    assert np.array_equal(got[~bad].T.astype(np.float64), host, equal_nan=True)
+    assert np.isnan(got[bad, 0]).all() and np.array_equal(got[bad, 1:], cloud[1:, bad].T, equal_nan=True)
+    image = torch.from_numpy(syn.colorize(syn.make_label_map(rng, H, W))).to(cuda_device)
+    a.frame_device(dev_pts, "velodyne", image, None, cam, src_kind="rgb")
+    b = make_sm(boundary, 0.2, syn.log_confusion(5), True, cuda_device)
+    b.frame_device(host, "velodyne", image, None, cam, src_kind="rgb")
+    assert torch.equal(a.map_dev, b.map_dev) and float(a.map_dev.abs().sum()) > 0
+    # through the callback: UNPACK_ON_DEVICE makes pcd_callback queue the device tensor
+    a.unpack_on_device = True
+    msg.header = type("H", (), {"frame_id": "velodyne", "stamp": 1.0})()
+    a.pcd_callback(msg)
+    assert a.pcd_queue[-1].is_cuda
+    assert torch.equal(torch.nan_to_num(a.pcd_queue[-1]), torch.nan_to_num(dev_pts))
+    # a different record layout and an empty cloud
+    msg2 = _pointcloud2(pts[:100], point_step=48, offsets=(24, 28, 32, 4))
+    d2, c2 = a.unpack_pointcloud2_device(msg2)
+    assert torch.equal(torch.nan_to_num(d2), torch.nan_to_num(dev_pts[:100])) and int(c2.item()) == int((~bad[:100]).sum())
+    d0, c0 = a.unpack_pointcloud2_device(_pointcloud2([]))
+    assert d0.shape[0] == 0 and int(c0.item()) == 0

@@ -212,3 +212,70 @@ def test_preprocessing_matches_restatement(cuda_device):
     got = preprocess_device(bgr, cam, 2).cpu().numpy().astype(np.int32)
     ref = po.preprocess(bgr, cam.K, cam.dist, 2).astype(np.int32)
     assert np.abs(got - ref).max() <= 1
+
+
+def test_node_with_ros_style_messages_and_two_camera_threads(state, cuda_device):
+    """The use_ros path of VisionSemanticSegmentationNode without ROS: a sensor_msgs/Image-like message (bytes payload with
+    row padding, height / width / step / encoding) is decoded, the colour image is published as an 8UC3 Image carrying the
+    INPUT header on that camera's publisher (:118-134), and two camera threads sharing one compiled plan never see each
+    other's labels (rospy runs every subscription's callback on its own thread; the reference's torch forward has no
+    shared buffers, this build's plan does -> a lock)."""
+    import threading
+    import types
+    from vision_semantic_segmentation_amd import SemanticSegmentation, VisionSemanticSegmentationNode, get_cfg_defaults
+    cfg = get_cfg_defaults()
+    seg = SemanticSegmentation(_cfg("bf16"), device=cuda_device, state_dict=state)
+    node = VisionSemanticSegmentationNode(cfg, seg=seg, undistort=False)
+
+    class FakeImage(object):
+        def __init__(self):
+            self.header = types.SimpleNamespace(stamp=None, frame_id=None)
+
+    class FakePub(object):
+        def __init__(self):
+            self.sent = []
+
+        def publish(self, m):
+            self.sent.append(m)
+
+    node._ros_image_cls, node.image_pub_cam1, node.image_pub_cam6 = FakeImage, FakePub(), FakePub()
+    H, W = 96, 128
+    rng = np.random.default_rng(3)
+    frames = {"camera1": rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8), "camera6": rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)}
+
+    def msg(frame_id, stamp):
+        step = W * 3 + 8
+        rows = np.zeros((H, step), dtype=np.uint8)
+        rows[:, :W * 3] = frames[frame_id].reshape(H, W * 3)
+        return types.SimpleNamespace(data=rows.tobytes(), height=H, width=W, step=step, encoding="bgr8", is_bigendian=0,
+                                     header=types.SimpleNamespace(stamp=stamp, frame_id=frame_id))
+
+    want = {k: node.image_callback(types.SimpleNamespace(data=v, header=types.SimpleNamespace(stamp=0, frame_id=k))) for k, v in frames.items()}
+    assert not np.array_equal(want["camera1"], want["camera6"])
+    node.image_pub_cam1.sent.clear()
+    node.image_pub_cam6.sent.clear()
+    errors = []
+
+    def worker(frame_id, n):
+        try:
+            for i in range(n):
+                out = node.image_callback(msg(frame_id, (frame_id, i)))
+                if not np.array_equal(out, want[frame_id]):
+                    errors.append("%s frame %d got another camera's labels" % (frame_id, i))
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k, 12)) for k in frames]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    for k, pub in (("camera1", node.image_pub_cam1), ("camera6", node.image_pub_cam6)):
+        assert len(pub.sent) == 12
+        m = pub.sent[5]
+        assert (m.height, m.width, m.step, m.encoding) == (H, W, W * 3, "8UC3") and m.header.frame_id == k and m.header.stamp == (k, 5)
+        assert np.array_equal(np.frombuffer(m.data, dtype=np.uint8).reshape(H, W, 3), want[k])
+    # an unknown camera is segmented (no undistortion) but has no publisher (:135-136)
+    node.image_callback(msg("camera1", 1).__class__(**dict(vars(msg("camera1", 1)), header=types.SimpleNamespace(stamp=1, frame_id="camera9"))))
+    assert len(node.image_pub_cam1.sent) == 12 and len(node.image_pub_cam6.sent) == 12

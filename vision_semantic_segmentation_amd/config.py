@@ -121,6 +121,8 @@ def get_cfg_defaults():
     C.MAPPING.PCD = CfgNode()
     C.MAPPING.PCD.USE_INTENSITY = True
     C.MAPPING.PCD.RANGE_MAX = 100.0
+    # build-specific: unpack PointCloud2 messages on the GPU (SemanticMapping.pcd then is a CUDA float32 [N,4] tensor)
+    C.MAPPING.PCD.UNPACK_ON_DEVICE = False
     C.MAPPING.CONFUSION_MTX = CfgNode()
     C.MAPPING.CONFUSION_MTX.LOAD_PATH = ""
     C.MAPPING.INPUT_DIR = ""

@@ -698,6 +698,45 @@ extern "C" int avl_pack_semantic_cloud(const double* pcd, const uint8_t* label, 
     return AVL_OK;
 }
 
+namespace {
+// One lane per point; fields are 4-byte aligned, so each is one dword load (a point's record is usually 16-32 bytes:
+// the wave reads a contiguous 1-2 KB).  The count goes through one ballot + one atomic per wave.
+__global__ void __launch_bounds__(kBlock) k_unpack_cloud(const unsigned char* __restrict__ data, long long n, int step, int ox, int oy,
+                                                         int oz, int oi, float4* __restrict__ out, int* __restrict__ n_valid) {
+    const long long k = (long long)blockIdx.x * kBlock + threadIdx.x;
+    bool ok = false;
+    if (k < n) {
+        const unsigned char* rec = data + k * step;
+        float x = *reinterpret_cast<const float*>(rec + ox);
+        const float y = *reinterpret_cast<const float*>(rec + oy), z = *reinterpret_cast<const float*>(rec + oz);
+        const float i = *reinterpret_cast<const float*>(rec + oi);
+        ok = !(x != x || y != y || z != z || i != i);
+        if (!ok) x = __uint_as_float(0x7fc00000u);
+        out[k] = make_float4(x, y, z, i);
+    }
+    if (n_valid) {
+        const unsigned long long b = __ballot(ok);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_valid, __popcll(b));
+    }
+}
+}  // namespace
+
+extern "C" int avl_unpack_pointcloud2(const uint8_t* data, int64_t n_points, int point_step, int off_x, int off_y, int off_z, int off_i,
+                                      float* out_xyzi, int32_t* n_valid, void* stream) {
+    AVL_REQUIRE(n_points >= 0, "n_points = %lld", (long long)n_points);
+    if (n_valid) AVL_HIP_CHECK(hipMemsetAsync(n_valid, 0, sizeof(int32_t), avl::as_stream(stream)));
+    if (n_points == 0) return AVL_OK;
+    AVL_REQUIRE(data && out_xyzi, "bad buffers");
+    AVL_REQUIRE(point_step >= 16 && point_step % 4 == 0, "point_step = %d (FLOAT32 fields need 4-byte aligned records)", point_step);
+    const int offs[4] = {off_x, off_y, off_z, off_i};
+    for (int o : offs) AVL_REQUIRE(o >= 0 && o % 4 == 0 && o + 4 <= point_step, "field offset %d outside a %d-byte record / unaligned", o, point_step);
+    AVL_REQUIRE(reinterpret_cast<uintptr_t>(data) % 4 == 0 && reinterpret_cast<uintptr_t>(out_xyzi) % 16 == 0, "unaligned buffers");
+    hipLaunchKernelGGL(k_unpack_cloud, dim3((unsigned)((n_points + kBlock - 1) / kBlock)), dim3(kBlock), 0, avl::as_stream(stream), data,
+                       (long long)n_points, point_step, off_x, off_y, off_z, off_i, reinterpret_cast<float4*>(out_xyzi), n_valid);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
 // ---------------------------------------------------------------------------------------- rendering
 namespace {
 int fill_render(RenderParams& rp, int C, const uint8_t* colors, const int32_t* priority, const double* thresholds) {

@@ -141,6 +141,9 @@ class SemanticMapping(object):
         self.pcd_time = None
         self.pcd_range_max = cfg.MAPPING.PCD.RANGE_MAX
         self.use_pcd_intensity = cfg.MAPPING.PCD.USE_INTENSITY
+        # build-specific: unpack PointCloud2 payloads on the GPU (self.pcd is then a CUDA float32 [N,4] tensor, not ndarray [4,N])
+        self.unpack_on_device = bool(getattr(cfg.MAPPING.PCD, "UNPACK_ON_DEVICE", False))
+        self._pc2_stage = None
 
         # map[x, y] (mapping.py:106-117)
         self._grid = None
@@ -258,12 +261,40 @@ class SemanticMapping(object):
             pts = np.asarray(msg.points)
             pcd = pts if pts.shape[0] == 4 else pts.T
             pcd = np.ascontiguousarray(pcd, dtype=np.float64)
+        elif self.unpack_on_device:
+            pcd = self.unpack_pointcloud2_device(msg)[0]       # float32 [N,4] in HBM; NaN points keep their slot, x = NaN
         else:
             pcd = unpack_pointcloud2(msg)
         with self._lock:
             self.pcd_queue.append(pcd)
             self.pcd_header_queue.append(msg.header)
             self.pcd_frame_id = msg.header.frame_id
+
+    def unpack_pointcloud2_device(self, msg, stream=None):
+        """pcd_callback's unpacking (mapping.py:172-183) on the GPU: the message payload is uploaded once (through a reused
+        pinned staging buffer, asynchronously on `stream`) and avl_unpack_pointcloud2 writes float32 [N,4] (x,y,z,intensity)
+        straight into the layout the fused frame reads.  Returns (points CUDA float32 [N,4], n_valid CUDA int32 [1]) --
+        n_valid is what read_points(skip_nans=True) would have yielded; points that it would have skipped keep their slot
+        with x = NaN and are rejected by the projection kernel."""
+        offs = {f.name: f.offset for f in msg.fields}
+        n = int(msg.width) * int(msg.height)
+        step = int(msg.point_step)
+        nbytes = n * step
+        points = torch.empty((max(n, 1), 4), dtype=torch.float32, device=self.device)[:n]
+        count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if n == 0:
+            return points, count
+        if self._pc2_stage is None or self._pc2_stage[0].numel() < nbytes:
+            cap = max(nbytes, 1 << 22)
+            self._pc2_stage = (torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device))
+        host, dev = self._pc2_stage
+        host.numpy()[:nbytes] = np.frombuffer(msg.data, dtype=np.uint8, count=nbytes)       # one memcpy into pinned memory
+        dev[:nbytes].copy_(host[:nbytes], non_blocking=True)
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        rc = _lib.lib().avl_unpack_pointcloud2(_ptr(dev), n, step, offs["x"], offs["y"], offs["z"], offs["intensity"], _ptr(points),
+                                               _ptr(count), C.c_void_p(s))
+        _lib.check(rc, "avl_unpack_pointcloud2")
+        return points, count
 
     @staticmethod
     def _nearest_in_queue(stamps, target_stamp):

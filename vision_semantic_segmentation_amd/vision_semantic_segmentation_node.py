@@ -7,6 +7,7 @@ colouring, publish.  Pre-processing is one HIP kernel (avl_preprocess_image), th
 (avl_colorize_labels); the frame is uploaded once and only the colour image comes back.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -76,6 +77,11 @@ class VisionSemanticSegmentationNode(object):
         self.publish = publish          # callable(frame_id, colour image, header) or None
         self.undistort = undistort      # the reference always undistorts camera1 / camera6 frames (:84-87)
         self.last_labels = None         # CUDA uint8 [h', w'] of the last frame (feeds the fused mapping path)
+        # rospy runs each subscription's callback on its own thread, and both cameras share one compiled plan (fixed
+        # input / activation / label buffers on one stream): one frame at a time through upload -> net -> colour -> download
+        self._lock = threading.Lock()
+        self._ros_image_cls = None
+        self.image_pub_cam1 = self.image_pub_cam6 = None
         if use_ros:
             self._setup_ros()
 
@@ -86,6 +92,22 @@ class VisionSemanticSegmentationNode(object):
         self.image_sub_cam6 = rospy.Subscriber("/camera6/image_raw", Image, self.image_callback)
         self.image_pub_cam1 = rospy.Publisher("/camera1/semantic", Image, queue_size=1)
         self.image_pub_cam6 = rospy.Publisher("/camera6/semantic", Image, queue_size=1)
+        self._ros_image_cls = Image
+
+    def _publish_ros(self, colored, header):
+        """:118-134 -- the colour image as an 8UC3 sensor_msgs/Image (cv_bridge's "passthrough" of a uint8 H x W x 3 array)
+        with the INPUT message's stamp and frame_id, on the publisher of that camera."""
+        pub = {"camera1": self.image_pub_cam1, "camera6": self.image_pub_cam6}.get(header.frame_id)
+        if pub is None:
+            return None                                           # :135-136: the reference only warns
+        out = self._ros_image_cls()
+        out.height, out.width = int(colored.shape[0]), int(colored.shape[1])
+        out.encoding, out.is_bigendian, out.step = "8UC3", 0, int(colored.shape[1]) * 3
+        out.data = np.ascontiguousarray(colored).tobytes()
+        out.header.stamp = header.stamp
+        out.header.frame_id = header.frame_id
+        pub.publish(out)
+        return out
 
     def _downscale_factor(self):
         """IMAGE_SCALE -> integer INTER_AREA factor (:92-98).  The reference's configs use 1.0 and 0.5."""
@@ -100,14 +122,23 @@ class VisionSemanticSegmentationNode(object):
         """:74-136.  msg.data: uint8[H,W,3] BGR (as the camera driver publishes it).  The whole chain runs on the GPU:
         pre-processing (:83-98), segmentation (:101-102), nearest upscale + palette (:109-116); only the published
         colour image comes back to the host.  Returns that uint8[H,W,3] image (also handed to ``publish``)."""
-        bgr = msg.data if isinstance(msg.data, (np.ndarray, torch.Tensor)) else np.asarray(msg.data)
+        if isinstance(msg.data, (np.ndarray, torch.Tensor)):
+            bgr = msg.data
+        else:                                         # a sensor_msgs/Image: bytes + height / width / step / encoding (:76-80)
+            from .mapping import _imgmsg_to_array
+            bgr = _imgmsg_to_array(msg)
+            if bgr.ndim != 3:
+                raise ValueError("image_callback needs a 3-channel image, got encoding %r" % (msg.encoding,))
         h, w = int(bgr.shape[0]), int(bgr.shape[1])
         cam = {"camera1": self.cam1, "camera6": self.cam6}.get(msg.header.frame_id)   # unknown frame ids: no undistortion (:88-89)
-        rgb_small = preprocess_device(bgr, cam if self.undistort else None, self._downscale_factor())
-        labels = self.seg.segmentation_device(rgb_small)
-        self.last_labels = labels
-        colored = colorize_labels_device(labels, h, w, self.seg_color_ref)
-        out = colored.cpu().numpy()
+        with self._lock:
+            rgb_small = preprocess_device(bgr, cam if self.undistort else None, self._downscale_factor())
+            labels = self.seg.segmentation_device(rgb_small)
+            self.last_labels = labels
+            colored = colorize_labels_device(labels, h, w, self.seg_color_ref)
+            out = colored.cpu().numpy()
         if self.publish is not None:
             self.publish(msg.header.frame_id, out, msg.header)                     # :129-134
+        if self._ros_image_cls is not None:
+            self._publish_ros(out, msg.header)
         return out
