@@ -147,6 +147,25 @@ __device__ __forceinline__ void cast_vote_nolist(unsigned* cell_mask, int cell, 
     if (cell >= 0 && vote != 0) atomicOr(&cell_mask[cell], vote);
 }
 
+// Byte-wide vote mask (dense-cloud path, when C class bits + the bonus bits fit 8): bit i = class i seen, bit C + r = lane
+// bonus of the r-th class of bonus_classes.  A quarter of the bytes of the 32-bit mask for the sweep to read; the OR goes
+// to the containing dword (idempotent, so any interleaving of lanes gives the same mask).
+__device__ __forceinline__ unsigned encode_vote_byte(unsigned vote, int C, unsigned bonus_classes) {
+    unsigned enc = vote & ((1u << C) - 1u);
+    unsigned rest = bonus_classes;
+    int r = 0;
+    while (rest) {
+        const int j = __builtin_ctz(rest);
+        rest &= rest - 1u;
+        if ((vote >> (16 + j)) & 1u) enc |= 1u << (C + r);
+        ++r;
+    }
+    return enc;
+}
+__device__ __forceinline__ void cast_vote_byte(unsigned* cell_mask, int cell, unsigned vote, int C, unsigned bonus_classes) {
+    if (cell >= 0 && vote != 0) atomicOr(&cell_mask[cell >> 2], encode_vote_byte(vote, C, bonus_classes) << ((cell & 3) * 8));
+}
+
 // ---------------------------------------------------------------- projection only (:367-383)
 __global__ void __launch_bounds__(kBlock) k_project_points(PtsView pv, ProjParams pp, int* __restrict__ out_ixy,
                                                            unsigned char* __restrict__ out_mask) {
@@ -261,7 +280,8 @@ __global__ void __launch_bounds__(kBlock) k_vote_labelled(const double* __restri
 }
 
 // ---------------------------------------------------------------- fused project + vote
-template <int SRC, bool LIST>
+// MODE: 0 = 32-bit mask + touched list, 1 = 32-bit mask only (sweep), 2 = byte mask only (sweep, see encode_vote_byte)
+template <int SRC, int MODE>
 __global__ void __launch_bounds__(kBlock) k_fused_vote(PtsView pv, ProjParams pp, GridParams g,
                                                        const unsigned char* __restrict__ src, int src_w, int src_h,
                                                        LutParams lut, unsigned* __restrict__ cell_mask,
@@ -290,8 +310,9 @@ __global__ void __launch_bounds__(kBlock) k_fused_vote(PtsView pv, ProjParams pp
             }
         }
     }
-    if (LIST) cast_vote(cell_mask, touched, counter, cell, vote);
-    else cast_vote_nolist(cell_mask, cell, vote);
+    if (MODE == 0) cast_vote(cell_mask, touched, counter, cell, vote);
+    else if (MODE == 1) cast_vote_nolist(cell_mask, cell, vote);
+    else cast_vote_byte(cell_mask, cell, vote, g.C, g.bonus_classes);
 }
 
 // ---------------------------------------------------------------- touched cells -> grid (:424,437)
@@ -350,6 +371,114 @@ __global__ void __launch_bounds__(kBlock) k_grid_apply_scan(MapT* __restrict__ m
             }
         }
         reinterpret_cast<uint4*>(cell_mask)[q] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+// Sweep of the BYTE mask.  The 32-bit sweep above is latency-bound (one dependent 16-byte load per lane and iteration, then
+// a serial read-modify-write chain in the few lanes that found something: 57 us for the 64 MB mask of config E).  Here a
+// workgroup takes 16 K cells at a time: every lane has four independent 16-byte mask loads in flight, the non-zero bytes
+// are compacted into an LDS list (local cell index << 8 | bits) with one LDS atomic each, the mask bytes are cleared,
+// and then ALL lanes apply one listed cell each: the grid rows are read, updated in the reference's class order
+// (class i, then its lane bonus) and written back with every lane busy and every load independent.
+constexpr int kSweepVec = 4;                                  // 16-byte mask vectors per lane and round
+constexpr int kSweepCells = kBlock * kSweepVec * 16;          // cells per workgroup round (16384)
+template <typename MapT>
+__global__ void __launch_bounds__(kBlock) k_grid_sweep_bytes(MapT* __restrict__ map, int C, unsigned bonus_classes, CmParams cm,
+                                                             unsigned char* __restrict__ mask, long long ncell, int exp) {
+    __shared__ unsigned list[kSweepCells];
+    __shared__ int count;
+    const long long rounds = (ncell + kSweepCells - 1) / kSweepCells;
+    for (long long rd = blockIdx.x; rd < rounds; rd += gridDim.x) {
+        if (threadIdx.x == 0) count = 0;
+        __syncthreads();
+        const long long base = rd * kSweepCells;
+        uint4 v[kSweepVec];
+#pragma unroll
+        for (int u = 0; u < kSweepVec; ++u) {
+            const long long c0 = base + ((long long)u * kBlock + threadIdx.x) * 16;
+            v[u] = c0 < ncell ? *reinterpret_cast<const uint4*>(mask + c0) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        // list slots: every lane counts its non-zero bytes, one ballot-free wave scan (shuffles) gives its offset inside the
+        // wave, ONE LDS atomic per wave reserves the wave's range -- instead of one returning LDS atomic per listed cell
+        int mine = 0;
+#pragma unroll
+        for (int u = 0; u < kSweepVec; ++u) {
+            const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned x = w4[q];
+                // one bit per non-zero byte: (x | x >> 1 | ... | x >> 7) & 0x01010101
+                unsigned t = x | (x >> 4);
+                t |= t >> 2;
+                t |= t >> 1;
+                mine += __builtin_popcount(t & 0x01010101u);
+            }
+        }
+        if (exp & 2) mine = 0;
+        const int lane = threadIdx.x & 63;
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        int wave_base = 0;
+        if (lane == 63 && incl > 0) wave_base = atomicAdd(&count, incl);
+        wave_base = __shfl(wave_base, 63);
+        int slot = wave_base + incl - mine;
+        if (mine > 0) {
+#pragma unroll
+            for (int u = 0; u < kSweepVec; ++u) {
+                if ((v[u].x | v[u].y | v[u].z | v[u].w) == 0u) continue;
+                const int local0 = (u * kBlock + threadIdx.x) * 16;
+                auto take = [&](unsigned x, int first) {          // the non-zero bytes of one dword -> list (registers only: no indexed arrays)
+                    while (x) {
+                        const int b = __builtin_ctz(x) >> 3;
+                        list[slot++] = ((unsigned)(local0 + first + b) << 8) | ((x >> (8 * b)) & 0xffu);
+                        x &= ~(0xffu << (8 * b));
+                    }
+                };
+                take(v[u].x, 0);
+                take(v[u].y, 4);
+                take(v[u].z, 8);
+                take(v[u].w, 12);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kSweepVec; ++u)
+            if ((v[u].x | v[u].y | v[u].z | v[u].w) != 0u)
+                *reinterpret_cast<uint4*>(mask + base + (u * kBlock + threadIdx.x) * 16) = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        const int n = (exp & 1) ? 0 : count;
+        for (int k = threadIdx.x; k < n; k += kBlock) {
+            const unsigned e = list[k];
+            const unsigned m = e & 0xffu;
+            MapT* row = map + (base + (e >> 8)) * C;
+            double vals[AVL_MAX_MAP_CLASSES];
+#pragma unroll
+            for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
+                if (c < C) vals[c] = (double)row[c];
+            int r = 0;
+            for (int i = 0; i < C; ++i) {
+                if (m & (1u << i)) {
+#pragma unroll
+                    for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
+                        if (c < C) vals[c] = (double)(MapT)(vals[c] + cm.cm[c * C + i]);
+                }
+                if ((bonus_classes >> i) & 1u) {
+                    if (m & (1u << (C + r))) {
+#pragma unroll
+                        for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
+                            if (c == i) vals[c] = (double)(MapT)(vals[c] + 2.0);
+                    }
+                    ++r;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
+                if (c < C) row[c] = (MapT)vals[c];
+        }
+        __syncthreads();
     }
 }
 
@@ -519,6 +648,32 @@ int launch_apply_scan(const avl_grid* g, const double* cm_host, hipStream_t s) {
     return AVL_OK;
 }
 
+int launch_sweep_bytes(const avl_grid* g, const double* cm_host, unsigned bonus, hipStream_t s) {
+    if (!cm_host) return avl::set_error(AVL_E_ARG, "cm_host is NULL");
+    CmParams cm;
+    memset(&cm, 0, sizeof(cm));
+    memcpy(cm.cm, cm_host, sizeof(double) * g->C * g->C);
+    const long long ncell = (long long)g->Hm * g->Wm;
+    const long long rounds = (ncell + kSweepCells - 1) / kSweepCells;
+    const unsigned blocks = (unsigned)(rounds < 2048 ? rounds : 2048);
+    unsigned char* mask = reinterpret_cast<unsigned char*>(g->cell_mask);
+    static const int exp = getenv("AVL_SWEEP_EXP") ? atoi(getenv("AVL_SWEEP_EXP")) : 0;      // timing experiments only
+    if (g->map_dtype == AVL_F64)
+        hipLaunchKernelGGL(k_grid_sweep_bytes<double>, dim3(blocks), dim3(kBlock), 0, s, static_cast<double*>(g->map), g->C, bonus, cm, mask, ncell, exp);
+    else
+        hipLaunchKernelGGL(k_grid_sweep_bytes<float>, dim3(blocks), dim3(kBlock), 0, s, static_cast<float*>(g->map), g->C, bonus, cm, mask, ncell, exp);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+// byte mask usable: class bits + bonus bits fit a byte, whole 16-byte vectors, aligned scratch
+bool byte_mask_ok(const avl_grid* g, unsigned bonus) {
+    static const char* mode = getenv("AVL_MASK_MODE");          // "32": keep the 32-bit mask (experiments)
+    if (mode && mode[0] == '3') return false;
+    const long long cells = (long long)g->Hm * g->Wm;
+    return g->C + __builtin_popcount(bonus) <= 8 && cells % 16 == 0 && (reinterpret_cast<uintptr_t>(g->cell_mask) & 15) == 0;
+}
+
 // list (sparse) vs sweep (dense) apply: the sweep reads Hm*Wm*4 bytes whatever the cloud; the list costs a
 // returning atomic + an append per first touch.  AVL_APPLY_MODE=list|scan overrides (experiments).
 bool use_scan(const avl_grid* g, int n) {
@@ -527,7 +682,9 @@ bool use_scan(const avl_grid* g, int n) {
     if (cells % 4 != 0 || (reinterpret_cast<uintptr_t>(g->cell_mask) & 15)) return false;
     if (mode && mode[0] == 'l') return false;
     if (mode && mode[0] == 's') return true;
-    return (long long)n * 128 >= cells;      // measured: sweep wins at 120 k points on 4 M cells (25 vs 36 us) and 1 M on 16 M (73 vs 213 us)
+    // measured (32-bit sweep): sweep wins at 120 k points on 4 M cells (25 vs 36 us) and 1 M on 16 M (73 vs 213 us); the byte
+    // sweep reads a quarter of that, so it stays ahead down to much sparser clouds
+    return (long long)n * (byte_mask_ok(g, 0) ? 1024 : 128) >= cells;
 }
 
 }  // namespace
@@ -646,15 +803,17 @@ extern "C" int avl_fused_frame(const avl_grid* g, const void* pts, int n, int dt
     if (n == 0) return AVL_OK;
     AVL_REQUIRE(g->touched_cap >= (n < g->Hm * g->Wm ? n : g->Hm * g->Wm), "touched_cap %d too small", g->touched_cap);
     hipStream_t s = avl::as_stream(stream);
-    AVL_HIP_CHECK(hipMemsetAsync(g->counter, 0, 16, s));
     const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
     const bool scan = use_scan(g, n);
-#define AVL_FV(SRC, LIST) hipLaunchKernelGGL((k_fused_vote<SRC, LIST>), grid, block, 0, s, pv, pp, gp, src, src_w, src_h, lut, g->cell_mask, g->touched, g->counter)
-    if (src_kind == AVL_SRC_RGB) { if (scan) AVL_FV(AVL_SRC_RGB, false); else AVL_FV(AVL_SRC_RGB, true); }
-    else { if (scan) AVL_FV(AVL_SRC_CLASSMAP, false); else AVL_FV(AVL_SRC_CLASSMAP, true); }
+    const int mode = !scan ? 0 : (byte_mask_ok(g, bonus_classes) ? 2 : 1);
+    if (mode == 0) AVL_HIP_CHECK(hipMemsetAsync(g->counter, 0, 16, s));      // only the touched-list path counts
+#define AVL_FV(SRC, MODE) hipLaunchKernelGGL((k_fused_vote<SRC, MODE>), grid, block, 0, s, pv, pp, gp, src, src_w, src_h, lut, g->cell_mask, g->touched, g->counter)
+    if (src_kind == AVL_SRC_RGB) { if (mode == 2) AVL_FV(AVL_SRC_RGB, 2); else if (mode == 1) AVL_FV(AVL_SRC_RGB, 1); else AVL_FV(AVL_SRC_RGB, 0); }
+    else { if (mode == 2) AVL_FV(AVL_SRC_CLASSMAP, 2); else if (mode == 1) AVL_FV(AVL_SRC_CLASSMAP, 1); else AVL_FV(AVL_SRC_CLASSMAP, 0); }
 #undef AVL_FV
     AVL_LAUNCH_CHECK();
-    return scan ? launch_apply_scan(g, cm_host, s) : launch_apply(g, cm_host, nullptr, 0, s);
+    if (mode == 2) return launch_sweep_bytes(g, cm_host, bonus_classes, s);
+    return mode == 1 ? launch_apply_scan(g, cm_host, s) : launch_apply(g, cm_host, nullptr, 0, s);
 }
 
 extern "C" int avl_colorize_labels(const uint8_t* labels, int lw, int lh, const uint8_t* palette_host, uint8_t* out,
