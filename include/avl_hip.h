@@ -242,6 +242,17 @@ typedef struct avl_seg_op {
     const void* in_lo;
     const void* in2_lo;
     void* out_lo;
+    /* w_split = 2 (GEMM on gfx950's block-scaled matrix cores): `weight` is the plain f16 hi part [w_rows][K]; the correction
+     * products run on MX-FP4 copies (OCP e2m1 elements, element 2i in the low nibble of byte i, one E8M0 scale per 32 values
+     * along K) at 4x the f16 rate: Q4(W lo) x Q4(in hi) and, when in_lo is set, Q4(W hi) x Q4(in lo).
+     * An "MX bundle" of a [rows][C] tensor (C % 256 == 0, dense rows) is laid out
+     *     [FP4 plane of the hi part: rows x C/2 bytes][its scales: C/256 x rows x 8 bytes][the same two for the lo part]
+     * w_mx: bundle of the weights (rows = w_rows; first Q4(W lo), then Q4(W hi)); in_mx: bundle of the input (rows = in_rows);
+     * out_mx (GEMM with w_split = 2, or GCONV with w_split = 1): the op also writes the bundle of its OUTPUT (rows = out_rows;
+     * the lo half only if out_lo is set), which is what the next MX GEMM reads as in_mx. */
+    const void* w_mx;
+    const void* in_mx;
+    void* out_mx;
 } avl_seg_op;
 
 typedef struct avl_seg_plan avl_seg_plan;

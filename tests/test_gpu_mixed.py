@@ -287,3 +287,129 @@ def test_mixed_logits_within_1e3_of_oracle(state, hw, cuda_device):
     print("mixed %dx%d: max rel err %.3e, argmax agreement %.5f" % (hw[0], hw[1], rel, agree))
     assert rel <= 1e-3
     assert agree >= 0.998
+
+
+def _bundle(hi64, lo64, rows_pad):
+    """MX bundle [Q4(hi) | scales | Q4(lo) | scales] of a split tensor, rows padded with zeros"""
+    import torch
+    from vision_semantic_segmentation_amd.network import mx_quant_fp4
+    parts = []
+    for t in (hi64, lo64):
+        q, s = mx_quant_fp4(_pad_rows(t, rows_pad))
+        parts += [q.reshape(-1), s.reshape(-1)]
+    return torch.cat(parts)
+
+
+def _unbundle(buf, rows, c, half):
+    from vision_semantic_segmentation_amd.network import mx_bundle_bytes, mx_dequant_fp4
+    hb = mx_bundle_bytes(rows, c)
+    b = buf[half * hb:(half + 1) * hb]
+    q = b[:rows * (c // 2)].reshape(rows, c // 2)
+    s = b[rows * (c // 2):].reshape(c // 256, rows, 8)
+    return q, s, mx_dequant_fp4(q, s)
+
+
+@pytest.mark.parametrize("case", [  # (M, K, N, A split, residual split, out split, quantise output, relu)
+    (2600, 256, 512, False, None, False, False, True),
+    (2600, 256, 512, True, None, True, True, True),
+    (40000, 512, 1024, False, True, True, True, True),        # conv3-like: split residual and output, FP4 copy of the output
+    (70000, 1024, 256, True, None, False, False, True),       # conv1-like: both corrections
+    (300, 2048, 2048, True, False, True, True, False),        # fewer rows than one tile, single-plane residual
+])
+def test_mx_gemm(case, cuda_device):
+    """w_split = 2: main product on f16 hi parts, corrections Q4(W lo) x Q4(x hi) [+ Q4(W hi) x Q4(x lo)] on the block-scaled
+    matrix cores.  Reference: float64 evaluation of exactly that sum on the operands the kernel is given."""
+    import torch
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import OP_GEMM, AvlSegOp, mx_dequant_fp4, mx_quant_fp4, pack_mx_weights
+    M, K, N, a_split, r_split, o_split, quant_out, relu = case
+    g = torch.Generator().manual_seed(M + K + N)
+    Mp = (M + 255) // 256 * 256
+    a64 = torch.randn((M, K), generator=g, dtype=torch.float64) * torch.exp2(torch.randint(-3, 4, (M, 1), generator=g).double())
+    a_hi, a_lo = _split(a64)
+    if not a_split:
+        a_lo = torch.zeros_like(a_lo)
+    w64 = torch.randn((N, K), generator=g, dtype=torch.float64) / K ** 0.5
+    w_hi16, wbundle = pack_mx_weights(w64)
+    w_hi, w_lo = _split(w64)
+    b = torch.randn(N, generator=g)
+    deq = lambda t: mx_dequant_fp4(*mx_quant_fp4(t.double()))            # noqa: E731
+    ref = a_hi.double() @ w_hi.double().t() + deq(_pad_rows(a_hi, Mp))[:M] @ deq(w_lo).t() + b.double()
+    if a_split:
+        ref = ref + deq(_pad_rows(a_lo, Mp))[:M] @ deq(w_hi).t()
+    if r_split is not None:
+        r64 = torch.randn((M, N), generator=g, dtype=torch.float64)
+        r_hi, r_lo = _split(r64)
+        ref = ref + r_hi.double() + (r_lo.double() if r_split else 0)
+    if relu:
+        ref = torch.relu(ref)
+    planes = torch.stack([_pad_rows(a_hi, Mp), _pad_rows(a_lo, Mp)]).to(cuda_device)
+    in_mx = _bundle(a_hi, a_lo, Mp).to(cuda_device)
+    wd, wmx, bd = w_hi16.to(cuda_device), wbundle.to(cuda_device), b.to(cuda_device)
+    out = torch.full((2, Mp, N), 7.0, dtype=torch.float16, device=cuda_device)
+    from vision_semantic_segmentation_amd.network import mx_bundle_bytes
+    out_mx = torch.full((2 * mx_bundle_bytes(Mp, N),), 0xEE, dtype=torch.uint8, device=cuda_device)
+    op = AvlSegOp()
+    op.kind, op.dtype = OP_GEMM, _lib.AVL_F16
+    op.in_, op.out, op.weight, op.bias = planes[0].data_ptr(), out[0].data_ptr(), wd.data_ptr(), bd.data_ptr()
+    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = 1, M, K, K, Mp
+    op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = 1, M, N, N, Mp
+    op.relu, op.w_rows, op.ksize, op.stride, op.dil, op.groups = int(relu), N, 1, 1, 1, 1
+    op.w_split, op.w_mx, op.in_mx = 2, wmx.data_ptr(), in_mx.data_ptr()
+    if a_split:
+        op.in_lo = planes[1].data_ptr()
+    if o_split:
+        op.out_lo = out[1].data_ptr()
+    if quant_out:
+        op.out_mx = out_mx.data_ptr()
+    if r_split is not None:
+        rd = torch.stack([_pad_rows(r_hi, Mp), _pad_rows(r_lo, Mp)]).to(cuda_device)
+        op.in2, op.in2_ld = rd[0].data_ptr(), N
+        if r_split:
+            op.in2_lo = rd[1].data_ptr()
+    _run_plan([op])
+    got = out[0, :M].cpu().double() + (out[1, :M].cpu().double() if o_split else 0)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= (TOL if o_split else 2 ** -11 * 1.5), "mx gemm %s: %.3e" % (case, err)
+    assert torch.all(out[0, M:] == 7.0)
+    if quant_out:
+        # the FP4 copy of the output equals the host quantisation of the planes the kernel wrote, byte for byte
+        for half, plane in ((0, out[0]),) + (((1, out[1]),) if o_split else ()):
+            q_dev, s_dev, v_dev = _unbundle(out_mx.cpu(), Mp, N, half)
+            q_ref, s_ref = mx_quant_fp4(plane[:M].cpu().double())
+            assert torch.equal(s_dev[:, :M], s_ref), "scales of plane %d differ" % half
+            assert torch.equal(v_dev[:M], mx_dequant_fp4(q_ref, s_ref)), "FP4 plane %d differs" % half      # values: -0 == +0
+        assert torch.all(_unbundle(out_mx.cpu(), Mp, N, 0)[0][M:] == 0xEE)          # rows past M untouched
+
+
+@pytest.mark.parametrize("case", [(23, 45, 256, 1, 1), (30, 41, 512, 1, 2), (19, 67, 1024, 1, 4)])
+def test_grouped_conv_writes_the_mx_bundle(case, cuda_device):
+    import torch
+    from test_gpu_ops import _nhwc_rows, _spatial_op
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import OP_GCONV, mx_bundle_bytes, mx_quant_fp4, pack_gconv_windows
+    H, W, width, s, d = case
+    G = 32
+    cg = width // G
+    g = torch.Generator().manual_seed(H * 77 + W + width)
+    x = torch.randn((1, width, H, W), generator=g).to(torch.float16)
+    w64 = torch.randn((width, cg, 3, 3), generator=g, dtype=torch.float64) * (2.0 / (cg * 9)) ** 0.5
+    b = torch.randn(width, generator=g) * 0.1
+    w_hi, w_lo = _split(w64)
+    src = _nhwc_rows(x).to(cuda_device)
+    rows = (H * W + 255) // 256 * 256
+    dst = torch.zeros((2, rows, width), dtype=torch.float16, device=cuda_device)
+    mx = torch.full((2 * mx_bundle_bytes(rows, width),), 0xEE, dtype=torch.uint8, device=cuda_device)
+    nwin = width // 32
+    wd = torch.cat([pack_gconv_windows(w_hi.double(), G).reshape(nwin, 2, 9, 16, 32),
+                    pack_gconv_windows(w_lo.double(), G).reshape(nwin, 2, 9, 16, 32)], dim=2).reshape(-1).to(torch.float16).to(cuda_device)
+    bd = b.to(cuda_device)
+    _run_plan([_spatial_op(OP_GCONV, _lib.AVL_F16, src, (H, W), width, dst[0], (H, W), width, weight=wd.data_ptr(), bias=bd.data_ptr(),
+                           ksize=3, stride=s, pad=d, dil=d, groups=G, relu=1, w_layout=1, w_split=1, out_lo=dst[1].data_ptr(),
+                           out_mx=mx.data_ptr())])
+    M = H * W
+    for half in (0, 1):
+        q_dev, s_dev, v_dev = _unbundle(mx.cpu(), rows, width, half)
+        q_ref, s_ref = mx_quant_fp4(dst[half, :M].cpu().double())
+        from vision_semantic_segmentation_amd.network import mx_dequant_fp4
+        assert torch.equal(s_dev[:, :M], s_ref) and torch.equal(v_dev[:M], mx_dequant_fp4(q_ref, s_ref)), "plane %d" % half

@@ -20,6 +20,8 @@ from vision_semantic_segmentation_amd import network as N    # noqa: E402
 def rnd(x, kind):
     if kind == "f32":
         return x
+    if kind.startswith("mx"):            # outside the 1x1 convs the MX modes mean "weights split exactly"
+        kind = "f16x2"
     if kind == "f16":
         return x.to(torch.float16).to(torch.float32)
     if kind == "bf16":
@@ -38,6 +40,29 @@ def rnd(x, kind):
         lo = (x - hi - mid).to(torch.bfloat16).to(torch.float32)
         return hi + mid + lo
     raise ValueError(kind)
+
+
+def mx_quant(t, dim, fmt="fp4"):
+    """OCP MX block quantisation along `dim`: blocks of 32, shared power-of-two scale, e2m1 (fp4) or e2m3 (fp6) elements."""
+    t = t.movedim(dim, -1)
+    shp = t.shape
+    k = shp[-1]
+    pad = (-k) % 32
+    if pad:
+        t = F.pad(t, (0, pad))
+    b = t.reshape(-1, 32)
+    amax = b.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    scale = torch.exp2(torch.floor(torch.log2(amax)) - 2.0)          # max / scale in [4, 8)
+    v = (b / scale)
+    if fmt == "fp4":
+        grid = torch.tensor([0, 0.5, 1, 1.5, 2, 3, 4, 6.0])
+    else:
+        grid = torch.cat([torch.arange(0, 2, 0.125), torch.arange(2, 4, 0.25), torch.arange(4, 8, 0.5)])
+    mag = v.abs().clamp_max(float(grid[-1]))
+    idx = torch.bucketize(mag, (grid[1:] + grid[:-1]) / 2)
+    q = grid[idx] * torch.sign(v) * scale
+    q = q.reshape(*shp[:-1], k + pad)[..., :k]
+    return q.movedim(-1, dim)
 
 
 class Policy(object):
@@ -72,8 +97,22 @@ def forward(st, image_u8, pol):
 
     def conv(x, stage, ck, bn, relu=True, res=None, out_role="a", **kw):
         w, b = fold(st, ck, bn)
-        w = rnd(w.to(torch.float32), pol(stage, "w"))
-        y = F.conv2d(x, w, b.to(torch.float32), **kw)
+        wk = pol(stage, "w")
+        if wk.startswith("mx") and w.shape[2] == 1 and not kw.get("groups"):
+            # main pass on f16 hi parts, correction passes on MX-quantised operands: Q(W lo) Q(x hi) [+ Q(W hi) Q(x lo)]
+            fmt = "fp6" if wk.endswith("6") else "fp4"
+            w32 = w.to(torch.float32)
+            wh = rnd(w32, "f16")
+            wl = (w.to(torch.float64) - wh.to(torch.float64)).to(torch.float32)
+            xh = rnd(x, "f16")
+            xl = x - xh
+            y = F.conv2d(xh, wh, b.to(torch.float32), **kw)
+            y = y + F.conv2d(mx_quant(xh, 1, fmt), mx_quant(wl, 1, fmt), None, **kw)
+            if float(xl.abs().max()) > 0:
+                y = y + F.conv2d(mx_quant(xl, 1, fmt), mx_quant(wh, 1, fmt), None, **kw)
+        else:
+            w = rnd(w.to(torch.float32), "f16x2" if wk.startswith("mx") else wk)
+            y = F.conv2d(x, w, b.to(torch.float32), **kw)
         if res is not None:
             y = y + res
         if relu:
@@ -225,6 +264,21 @@ def main():
         report("+ l1-4 conv1 split, l1/2 conv2 split, stem w x2", Policy("f16", **dict(blocks(L12, "conv2", blocks(L34 + L12, "conv1", dict(d))), **{"stem:w": X})))
         report("+ all conv1, conv2 split", Policy("f16", **blocks(L34 + L12, "conv2", blocks(L34 + L12, "conv1", dict(d)))))
         report("+ all conv1, conv2 split, stem exact, aspp dw exact", Policy("f16", **dict(blocks(L34 + L12, "conv2", blocks(L34 + L12, "conv1", dict(d))), **{"stem": "f32", "aspp.b1.dw": "f32", "aspp.b2.dw": "f32", "aspp.b3.dw": "f32"})))
+    if sel == "mx":
+        def blocks(layers, conv, dd):
+            for li, nb in layers:
+                for b in range(nb):
+                    dd["layer%d.%d.%s:a" % (li, b, conv)] = "f32"
+            return dd
+        L34, L12 = ((3, 6), (4, 3)), ((1, 3), (2, 4))
+        for fmt in ("mx4", "mx6"):
+            d = {":w": fmt, ":t": "f32", ":ta": "f32", "stem": "f16", "dec": "f32", "dec:w": fmt,
+                 "aspp.b0:a": "f32", "aspp.proj:a": "f32"}
+            for i in (1, 2, 3):
+                d["aspp.b%d.dw" % i] = "f16"
+                d["aspp.b%d.pw:a" % i] = "f32"
+            report("built config, corrections in %s" % fmt, Policy("f16", **d))
+            report("  + all conv1, conv2 out split (%s)" % fmt, Policy("f16", **blocks(L34 + L12, "conv2", blocks(L34 + L12, "conv1", dict(d)))))
     print("den (max|logit|) = %.3f" % den)
 
 

@@ -27,6 +27,9 @@ struct GconvArgs {
     const float* bias;   // [C]
     HT* out;
     HT* out_lo;          // "mixed" precision: low plane of the result (value - f16(value)), or NULL
+    char* oq[2];         // MX-FP4 copies of the output planes for the next MX GEMM (avl_hip.h, w_split = 2), or NULL ...
+    char* os[2];         // ... and their E8M0 scales [C/256][rows][8]
+    long long o_srows;
     int H, W, in_ld, OH, OW, out_ld, C;
     int stride, dil;
     int th;              // output tile height (8, or 4 for stride 2)
@@ -146,10 +149,31 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs<HT> p) {
             }
             Vec8<HT>::store(p.out + ((long long)oy * p.OW + ox) * p.out_ld + cbase, v);
             if constexpr (WS != 0) {
-                if (p.out_lo) {
+                float lo[8];
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] -= (float)(HT)v[r];
-                    Vec8<HT>::store(p.out_lo + ((long long)oy * p.OW + ox) * p.out_ld + cbase, v);
+                for (int r = 0; r < 8; ++r) { const float h = (float)(HT)v[r]; lo[r] = (float)(HT)(v[r] - h); v[r] = h; }   // what the planes hold
+                if (p.out_lo) Vec8<HT>::store(p.out_lo + ((long long)oy * p.OW + ox) * p.out_ld + cbase, lo);
+                // FP4 copies: the window's 32 channels (the four kq lanes of this pixel) are one MX block
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    if (p.oq[pl] == nullptr) continue;
+                    const float* src = pl == 0 ? v : lo;
+                    float amax = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) amax = fmaxf(amax, fabsf(src[r]));
+                    amax = fmaxf(amax, __shfl_xor(amax, 16));
+                    amax = fmaxf(amax, __shfl_xor(amax, 32));
+                    const unsigned e = __float_as_uint(amax) >> 23;
+                    const unsigned sbyte = e >= 3u ? e - 2u : 1u;
+                    const float scale = __uint_as_float(sbyte << 23);
+                    unsigned pk = 0u;
+                    pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[0], src[1], scale, 0);
+                    pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[2], src[3], scale, 1);
+                    pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[4], src[5], scale, 2);
+                    pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[6], src[7], scale, 3);
+                    const long long pix = (long long)oy * p.OW + ox;
+                    *reinterpret_cast<unsigned*>(p.oq[pl] + pix * (p.C / 2) + cbase / 2) = pk;
+                    if (kq == 0) p.os[pl][((long long)(cbase >> 8) * p.o_srows + pix) * 8 + ((cbase >> 5) & 7)] = (char)sbyte;
                 }
             }
         }
@@ -172,6 +196,14 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
     a.bias = op.bias;
     a.out = static_cast<HT*>(op.out);
     a.out_lo = static_cast<HT*>(op.out_lo);
+    a.oq[0] = a.oq[1] = a.os[0] = a.os[1] = nullptr;
+    a.o_srows = op.out_rows;
+    if (op.out_mx) {
+        char* b = static_cast<char*>(op.out_mx);
+        const long long rows = op.out_rows, P = rows * (op.out_c / 2), S = (long long)(op.out_c / 256) * rows * 8;
+        a.oq[0] = b; a.os[0] = b + P;
+        if (op.out_lo) { a.oq[1] = b + P + S; a.os[1] = b + 2 * P + S; }
+    }
     a.H = op.in_h; a.W = op.in_w; a.in_ld = op.in_ld; a.OH = op.out_h; a.OW = op.out_w; a.out_ld = op.out_ld; a.C = op.in_c;
     a.stride = op.stride; a.dil = op.dil;
     a.comb = (op.stride == 1 && op.dil > 1 && op.pad == op.dil) ? 1 : 0;
@@ -197,6 +229,7 @@ int validate_gconv_mfma(const avl_seg_op& op) {
     AVL_REQUIRE(op.in_c % CC == 0, "MFMA grouped conv needs channels %% 64 == 0 (got %d)", op.in_c);
     AVL_REQUIRE(!op.w_split || op.dtype == AVL_F16, "split weights need AVL_F16 activations");
     AVL_REQUIRE(!op.in_lo && !op.in2_lo && (!op.out_lo || op.w_split), "grouped conv: only the output may be split, and only with w_split");
+    AVL_REQUIRE(!op.out_mx || (op.w_split == 1 && op.out_c % 256 == 0 && op.out_ld == op.out_c), "grouped conv: out_mx needs w_split, channels %% 256 == 0 and a dense output");
     const int cg = op.in_c / op.groups;
     AVL_REQUIRE(cg <= 32 && 32 % cg == 0, "MFMA grouped conv needs <= 32 channels per group dividing 32 (got %d)", cg);
     int th;

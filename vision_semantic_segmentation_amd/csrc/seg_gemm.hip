@@ -19,6 +19,7 @@
 //   * T = bf16 : v_mfma_f32_16x16x32_bf16, fp32 accumulate.
 //     T = float: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) -- the reference-precision mode.
 #include <cstdlib>
+#include <cstring>
 
 #include "seg_types.h"
 
@@ -529,6 +530,334 @@ int launch_cfg(const GemmArgs& a, int mtiles, hipStream_t s) {
     return AVL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// MX variant of the 256 x 256 ring GEMM ("mixed" precision, layer3 / layer4 / ASPP 1x1 convs).
+//
+//   out = W . x   with  W = Wh + Wl,  x = xh (+ xl)   (f16 pairs)
+//       ~ Wh.xh                                  main pass:   v_mfma_f32_16x16x32_f16, K blocks of 64
+//       + Q4(Wl).Q4(xh)  [+ Q4(Wh).Q4(xl)]       corrections: v_mfma_scale_f32_16x16x128_f8f6f4 on MX-FP4 operands
+//
+// The correction terms are 2^-11 of the result, so 2-3 significant bits are plenty for them (tools/precision_study.py:
+// the logits error does not move): FP4 (e2m1) with one power-of-two scale per 32 values along K, which the CDNA4 matrix
+// cores multiply at 4x the f16 rate -- a correction pass costs a quarter of an f16 pass instead of a whole one.
+// The scaled MFMA has the same C/D register layout as the f16 one, so all passes accumulate into the same registers.
+//
+// Data: an FP4 plane is [rows][K/2] bytes (element 2i in the low nibble of byte i); its scales are E8M0 bytes laid out
+// [K/256][rows][8] so that a 256-row tile's scales for one sub-step are 2 KB contiguous.  In LDS an FP4 tile is 256 rows
+// x 128 B = 256 K-values per row: exactly the geometry (DMA, XOR swizzle, fragment addressing) of an f16 tile with 64.
+// One K macro-block of 256 therefore is 4 f16 sub-steps + 1 or 2 FP4 sub-steps, every one of them "DMA a 32 KB
+// activation tile and a 32 KB weight tile, 64 MFMAs per wave".  Two ring stages, vmcnt(0) waits (no hand-counted
+// immediates here: the scale DMAs make the per-wave instruction count non-uniform).
+struct MxArgs {
+    GemmArgs g;                 // A = x hi plane (f16), W = W hi [N][K] f16 (plain rows), R / R_lo, C / C_lo as usual
+    const char* Aq[2];          // FP4 planes of the input: Q4(x hi), Q4(x lo) (second one only when nmx == 2)
+    const char* As[2];          // their scales
+    const char* Wq[2];          // FP4 weights paired with them: Q4(W lo), Q4(W hi)
+    const char* Ws[2];
+    int ldaq;                   // bytes per row of the input FP4 planes
+    long long a_srows, w_srows; // rows per K macro-block in the scale arrays (allocated rows)
+    char* Cq[2];                // FP4 planes of the OUTPUT (hi part, lo part) and their scales, or NULL
+    char* Cs[2];
+    int ldcq;
+    long long c_srows;
+    int nmx;                    // correction passes: 1 (weights only) or 2 (input split as well)
+};
+
+__device__ __forceinline__ void glds16_saddr(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+        : "memory");
+}
+
+// 16 values of one lane + the 16 of its partner (lane ^ 16) form one MX block: shared E8M0 scale, e2m1 elements.
+// Returns the scale byte; q[0..1] = the lane's 16 values packed (element 2i in the low nibble of byte i).
+__device__ __forceinline__ unsigned quantize_fp4_block(const float (&v)[16], unsigned (&q)[2]) {
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+    amax = fmaxf(amax, __shfl_xor(amax, 16));
+    const unsigned e = __float_as_uint(amax) >> 23;
+    const unsigned sbyte = e >= 3u ? e - 2u : 1u;            // 2^(floor(log2 amax) - 2): the block maximum lands in [4, 8) -> 4 or 6
+    const float scale = __uint_as_float(sbyte << 23);
+    q[0] = q[1] = 0u;
+#define AVL_FP4_PAIR(i)                                                                                  \
+    q[0] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q[0], v[2 * (i)], v[2 * (i) + 1], scale, (i));        \
+    q[1] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q[1], v[8 + 2 * (i)], v[8 + 2 * (i) + 1], scale, (i))
+    AVL_FP4_PAIR(0); AVL_FP4_PAIR(1); AVL_FP4_PAIR(2); AVL_FP4_PAIR(3);
+#undef AVL_FP4_PAIR
+    return sbyte;
+}
+
+template <int IO>
+__global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
+    typedef f16 H;
+    typedef typename Half16<H>::v8 v8;
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    constexpr int WM = 2, WN = 4, MI = 8, STAGES = 2;
+    constexpr int NW = WM * WN, BM = WM * MI * 16, BN = WN * 64;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
+    constexpr int W_REGION = STAGES * A_BYTES, S_REGION = W_REGION + STAGES * W_BYTES;      // [A tiles][W tiles][scale blocks]
+    constexpr int S_BYTES = 4096;                                                            // A scales 2 KB | W scales 2 KB
+    constexpr int A_INSTR = BM / 8 / NW, W_INSTR = BN / 8 / NW;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const GemmArgs& p = q.g;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nwg = gridDim.x;
+    int vb;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3, qq = nwg >> 3, r = nwg & 7;
+        vb = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + local;
+    }
+    const int total = mtiles * p.ntiles;
+    const int nmb = p.K / 256;                 // K macro-blocks per tile
+    const int nsub = 4 + q.nmx;                // sub-steps per macro-block: 4 f16 + the FP4 corrections
+    const unsigned lds_base = lds_addr(lds);
+
+    // ---- producer: per-lane byte offsets inside a tile (SGPR tile base + VGPR offset addressing)
+    const int srow = lane >> 3, schunk = lane & 7;
+    unsigned a_off16[A_INSTR], a_offq[A_INSTR], w_off16[W_INSTR], w_offq[W_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int r = (i * NW + wave) * 8 + srow;
+        a_off16[i] = (unsigned)r * (unsigned)(p.lda * 2) + ((schunk ^ (r & 7)) << 4);
+        a_offq[i] = (unsigned)r * (unsigned)q.ldaq + ((schunk ^ (r & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < W_INSTR; ++i) {
+        const int r = (i * NW + wave) * 8 + srow;
+        const int key = ((r >> 1) & 1) | (((r >> 4) & 3) << 1);
+        w_off16[i] = (unsigned)r * (unsigned)(p.K * 2) + ((schunk ^ key) << 4);
+        w_offq[i] = (unsigned)r * (unsigned)(p.K / 2) + ((schunk ^ key) << 4);
+    }
+    int pt = vb, pmb = 0, pj = 0, issued = 0;
+    auto issue = [&]() {
+        const int nt = pt % p.ntiles, mt = pt / p.ntiles;
+        const unsigned abase = lds_base + (issued % STAGES) * A_BYTES + wave * 1024;
+        const unsigned wbase = lds_base + W_REGION + (issued % STAGES) * W_BYTES + wave * 1024;
+        if (pj < 4) {
+            const char* sa = static_cast<const char*>(p.A) + (long long)mt * BM * p.lda * 2 + (long long)(pmb * 4 + pj) * 128;
+            const char* sw = static_cast<const char*>(p.W) + (long long)nt * BN * p.K * 2 + (long long)(pmb * 4 + pj) * 128;
+#pragma unroll
+            for (int i = 0; i < A_INSTR; ++i) glds16_saddr(sa, a_off16[i], abase + i * NW * 1024);
+#pragma unroll
+            for (int i = 0; i < W_INSTR; ++i) glds16_saddr(sw, w_off16[i], wbase + i * NW * 1024);
+        } else {
+            const int t = pj - 4;
+            const char* sa = q.Aq[t] + (long long)mt * BM * q.ldaq + (long long)pmb * 128;
+            const char* sw = q.Wq[t] + (long long)nt * BN * (p.K / 2) + (long long)pmb * 128;
+#pragma unroll
+            for (int i = 0; i < A_INSTR; ++i) glds16_saddr(sa, a_offq[i], abase + i * NW * 1024);
+#pragma unroll
+            for (int i = 0; i < W_INSTR; ++i) glds16_saddr(sw, w_offq[i], wbase + i * NW * 1024);
+            // scales: 2 KB for the activation rows (waves 0, 1), 2 KB for the weight rows (waves 2, 3)
+            if (wave < 4) {
+                const char* ss = wave < 2 ? q.As[t] + ((long long)pmb * q.a_srows + (long long)mt * BM) * 8 + wave * 1024
+                                          : q.Ws[t] + ((long long)pmb * q.w_srows + (long long)nt * BN) * 8 + (wave - 2) * 1024;
+                glds16_saddr(ss, (unsigned)lane * 16u, lds_base + S_REGION + (issued % STAGES) * S_BYTES + wave * 1024);
+            }
+        }
+        ++issued;
+        if (++pj == nsub) {
+            pj = 0;
+            if (++pmb == nmb) { pmb = 0; pt += nwg; }
+        }
+    };
+    if (pt < total) issue();
+
+    // ---- consumer
+    // fragment addressing: row r of a tile sits at r * 128 with its 16-byte chunks XOR-swizzled by key(r); the keys and the
+    // scale addresses (r * 8) are recomputed from the row offsets instead of being kept in registers (the 128
+    // accumulators leave little room: every array here is sized to stay clear of spills)
+    const int fr = lane & 15, kq = lane >> 4;
+    const int a_row0 = wm * (MI * 16) + fr;                       // + 16 mi
+    int w_off[4], w_key[4];
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) {
+        const int row = wn * 64 + (fr >> 2) * 16 + nj * 4 + (fr & 3);
+        w_off[nj] = W_REGION + row * 128;
+        w_key[nj] = ((row >> 1) & 1) | (((row >> 4) & 3) << 1);
+    }
+    const int a_key = a_row0 & 7;                                  // (a_row0 + 16 mi) & 7 is the same for every mi
+    f32x4 acc[MI][4];
+    auto init_acc = [&](int t) {
+        const int nb = (t % p.ntiles) * BN + wn * 64 + kq * 16;
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + nb + 4 * nj);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][nj] = f32x4{b.x, b.y, b.z, b.w};
+        }
+    };
+    if (vb < total) init_acc(vb);
+
+    int g = 0;
+    for (int t = vb; t < total; t += nwg) {
+        const int nt = t % p.ntiles, mt = t / p.ntiles;
+        // two plain loops per macro-block (f16 sub-steps, then FP4 sub-steps) rather than one loop with an if / else on the
+        // sub-step kind: the accumulators then have ONE definition chain (an if / else made hipcc keep two copies of them)
+        for (int mb = 0; mb < nmb; ++mb) {
+            for (int j = 0; j < 4; ++j, ++g) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // sub-step g has landed (this wave's share)
+                __builtin_amdgcn_s_barrier();
+                if (pt < total) issue();                                // sub-step g+1 -> the slots read during step g-1
+                const char* abase = lds + (g % STAGES) * A_BYTES + a_row0 * 128;
+                const char* wbase = lds + (g % STAGES) * W_BYTES;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    v8 wf[4];
+#pragma unroll
+                    for (int nj = 0; nj < 4; ++nj) wf[nj] = *reinterpret_cast<const v8*>(wbase + w_off[nj] + (((kk * 4 + kq) ^ w_key[nj]) << 4));
+                    const int achunk = ((kk * 4 + kq) ^ a_key) << 4;
+                    v8 af = *reinterpret_cast<const v8*>(abase + achunk);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const v8 cur = af;
+                        if (mi + 1 < MI) af = *reinterpret_cast<const v8*>(abase + (mi + 1) * 2048 + achunk);
+#pragma unroll
+                        for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<H>::mfma(wf[nj], cur, acc[mi][nj]);
+                    }
+                }
+            }
+            for (int u = 0; u < q.nmx; ++u, ++g) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (pt < total) issue();
+                const char* abase = lds + (g % STAGES) * A_BYTES + a_row0 * 128;
+                const char* wbase = lds + (g % STAGES) * W_BYTES;
+                const char* sbase = lds + (g % STAGES) * S_BYTES + S_REGION;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    int4 wf[4];
+                    int ws[4];
+#pragma unroll
+                    for (int nj = 0; nj < 4; ++nj) {
+                        wf[nj] = *reinterpret_cast<const int4*>(wbase + w_off[nj] + (((kk * 4 + kq) ^ w_key[nj]) << 4));
+                        ws[nj] = (int)((*reinterpret_cast<const unsigned*>(sbase + 2048 + ((w_off[nj] - W_REGION) >> 4) + kk * 4) >> (8 * kq)) & 0xffu);
+                    }
+                    const int achunk = ((kk * 4 + kq) ^ a_key) << 4;
+                    int4 af = *reinterpret_cast<const int4*>(abase + achunk);
+                    unsigned asw = *reinterpret_cast<const unsigned*>(sbase + a_row0 * 8 + kk * 4);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int4 cur = af;
+                        const int as = (int)((asw >> (8 * kq)) & 0xffu);
+                        if (mi + 1 < MI) {
+                            af = *reinterpret_cast<const int4*>(abase + (mi + 1) * 2048 + achunk);
+                            asw = *reinterpret_cast<const unsigned*>(sbase + (a_row0 + (mi + 1) * 16) * 8 + kk * 4);
+                        }
+                        const v8i xa = {cur.x, cur.y, cur.z, cur.w, 0, 0, 0, 0};
+#pragma unroll
+                        for (int nj = 0; nj < 4; ++nj) {
+                            const v8i wa = {wf[nj].x, wf[nj].y, wf[nj].z, wf[nj].w, 0, 0, 0, 0};
+                            acc[mi][nj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, acc[mi][nj], 4, 4, 0, ws[nj], 0, as);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- epilogue: bias is in the accumulators; residual (one or two planes), ReLU, f16 hi [+ lo] planes, and the
+        // FP4 planes + scales the next MX GEMM reads
+        const int nbase = nt * BN + wn * 64 + kq * 16;
+        const bool ncol_ok = nbase + 16 <= p.N;
+        const bool rsplit = p.R_lo != nullptr, csplit = p.C_lo != nullptr;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = mt * BM + wm * (MI * 16) + mi * 16 + fr;
+            const bool live = m < p.M && ncol_ok;
+            float v[16];
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[nj * 4 + r] = acc[mi][nj][r];
+            if (p.R && live) {
+                const H* rp = static_cast<const H*>(p.R) + (long long)m * p.ldr + nbase;
+                const v8 r0 = *reinterpret_cast<const v8*>(rp), r1 = *reinterpret_cast<const v8*>(rp + 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { v[i] += (float)r0[i]; v[8 + i] += (float)r1[i]; }
+                if (rsplit) {
+                    const H* rl = static_cast<const H*>(p.R_lo) + (long long)m * p.ldr + nbase;
+                    const v8 l0 = *reinterpret_cast<const v8*>(rl), l1 = *reinterpret_cast<const v8*>(rl + 8);
+                    // hi + lo first (exact in fp32), then the accumulator: same order as k_gemm_ring
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        v[i] = acc[mi][i >> 2][i & 3] + ((float)r0[i] + (float)l0[i]);
+                        v[8 + i] = acc[mi][2 + (i >> 2)][i & 3] + ((float)r1[i] + (float)l1[i]);
+                    }
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+            }
+            float hi[16], lo[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { hi[i] = (float)(H)v[i]; lo[i] = (float)(H)(v[i] - hi[i]); }      // the values the two planes hold
+            if (live) {
+                H* cp = static_cast<H*>(p.C) + (long long)m * p.ldc + nbase;
+                float a8[8], b8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { a8[i] = hi[i]; b8[i] = hi[8 + i]; }
+                Vec8<H>::store(cp, a8);
+                Vec8<H>::store(cp + 8, b8);
+                if (csplit) {
+                    H* cl = static_cast<H*>(p.C_lo) + (long long)m * p.ldc + nbase;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { a8[i] = lo[i]; b8[i] = lo[8 + i]; }
+                    Vec8<H>::store(cl, a8);
+                    Vec8<H>::store(cl + 8, b8);
+                }
+            }
+            if constexpr (IO != 0) {
+                // every lane takes part in the shuffles (rows past M quantise zeros and store nothing)
+                if (!live) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) hi[i] = lo[i] = 0.f;
+                }
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    if (q.Cq[pl] == nullptr) continue;
+                    unsigned pk[2];
+                    const unsigned sb = quantize_fp4_block(pl == 0 ? hi : lo, pk);
+                    if (live) {
+                        *reinterpret_cast<uint2*>(q.Cq[pl] + (long long)m * q.ldcq + nbase / 2) = make_uint2(pk[0], pk[1]);
+                        if ((kq & 1) == 0)
+                            q.Cs[pl][((long long)(nbase >> 8) * q.c_srows + m) * 8 + ((nbase >> 5) & 7)] = (char)sb;
+                    }
+                }
+            }
+        }
+        if (t + nwg < total) init_acc(t + nwg);
+    }
+}
+
+int launch_ring_mx(const MxArgs& a0, bool quantize_out, hipStream_t s) {
+    constexpr int LDS = 2 * (256 + 256) * 128 + 2 * 4096;
+    MxArgs a = a0;
+    a.g.ntiles = a.g.N / 256;
+    const int mtiles = (a.g.M + 255) / 256;
+    const int total = mtiles * a.g.ntiles;
+    const int grid = total < 256 ? total : 256;
+    if (quantize_out) {
+        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring_mx<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        hipLaunchKernelGGL(k_gemm_ring_mx<1>, dim3(grid), dim3(512), LDS, s, a, mtiles);
+    } else {
+        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring_mx<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        hipLaunchKernelGGL(k_gemm_ring_mx<0>, dim3(grid), dim3(512), LDS, s, a, mtiles);
+    }
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
 struct TileCfg { int bm, bn; };
 inline TileCfg pick_tile(const avl_seg_op& op);
 inline bool ring_eligible(const avl_seg_op& op) {
@@ -559,7 +888,17 @@ int validate_gemm(const avl_seg_op& op) {
     AVL_REQUIRE(op.out_rows >= M, "GEMM writes %d rows, output has %d", M, op.out_rows);
     if (!op.out_f32) AVL_REQUIRE((op.out_ld * es) % 16 == 0 && N % 16 == 0, "GEMM out_ld %d / N %d not 16-aligned", op.out_ld, N);
     if (op.in2) AVL_REQUIRE(op.in2_ld >= N && (op.in2_ld * es) % 16 == 0, "GEMM residual ld %d", op.in2_ld);
-    if (op.w_split || op.in_lo || op.in2_lo || op.out_lo) {
+    if (op.w_split == 2) {
+        AVL_REQUIRE(op.dtype == AVL_F16 && op.w_mx && op.in_mx, "MX GEMM needs AVL_F16 activations and the w_mx / in_mx bundles");
+        AVL_REQUIRE(K % 256 == 0 && N % 256 == 0 && op.w_rows % 256 == 0 && op.w_rows >= N, "MX GEMM: K %d, N %d, w_rows %d must be multiples of 256", K, N, op.w_rows);
+        AVL_REQUIRE(op.in_ld == K && op.in_rows % 256 == 0 && op.in_rows >= M, "MX GEMM input must be dense rows padded to 256 (ld %d, rows %d)", op.in_ld, op.in_rows);
+        AVL_REQUIRE(!op.out_f32 && op.out_ld >= N && (op.out_ld * 2) % 16 == 0, "MX GEMM output");
+        AVL_REQUIRE(!op.out_mx || op.out_ld == N, "MX GEMM can only quantise a dense output (out_ld %d, N %d)", op.out_ld, N);
+        AVL_REQUIRE((long long)op.in_rows * K * 2 < 0xffffff00LL && (long long)op.w_rows * K * 2 < 0xffffff00LL, "MX GEMM operand larger than 4 GB");
+        AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.w_mx) | reinterpret_cast<uintptr_t>(op.in_mx) | reinterpret_cast<uintptr_t>(op.out_mx) |
+                     reinterpret_cast<uintptr_t>(op.in_lo) | reinterpret_cast<uintptr_t>(op.in2_lo) | reinterpret_cast<uintptr_t>(op.out_lo)) % 16 == 0,
+                    "MX GEMM bundles / low planes must be 16-byte aligned");
+    } else if (op.w_split || op.in_lo || op.in2_lo || op.out_lo) {
         AVL_REQUIRE(op.dtype == AVL_F16 && op.w_split == 1, "split (hi + lo) operands need AVL_F16 activations and w_split = 1");
         AVL_REQUIRE(!op.in2_lo || op.in2, "in2_lo without in2");
         AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.in_lo) | reinterpret_cast<uintptr_t>(op.in2_lo) | reinterpret_cast<uintptr_t>(op.out_lo)) % 16 == 0,
@@ -579,6 +918,35 @@ int launch_gemm(const avl_seg_op& op, hipStream_t s) {
     a.lda = op.in_ld; a.ldr = op.in2_ld; a.ldc = op.out_ld;
     a.M = op.out_h * op.out_w; a.N = op.out_c; a.K = op.in_c;
     a.relu = op.relu; a.out_f32 = op.out_f32;
+    if (op.w_split == 2) {
+        MxArgs mx;
+        memset(&mx, 0, sizeof(mx));
+        a.nsub = 1;
+        a.a_lo_delta = 0;
+        a.R_lo = op.in2_lo; a.C_lo = op.out_lo;
+        mx.g = a;
+        const long long K = a.K, kb = K / 256;
+        auto bundle = [&](const void* base, long long rows, const char** plane, const char** scales) {
+            const char* b = static_cast<const char*>(base);
+            const long long P = rows * (K / 2), S = kb * rows * 8;
+            plane[0] = b; scales[0] = b + P; plane[1] = b + P + S; scales[1] = b + 2 * P + S;
+        };
+        bundle(op.in_mx, op.in_rows, mx.Aq, mx.As);
+        bundle(op.w_mx, op.w_rows, mx.Wq, mx.Ws);
+        mx.ldaq = (int)(K / 2);
+        mx.a_srows = op.in_rows;
+        mx.w_srows = op.w_rows;
+        mx.nmx = op.in_lo ? 2 : 1;
+        if (op.out_mx) {
+            char* b = static_cast<char*>(op.out_mx);
+            const long long rows = op.out_rows, P = rows * (a.N / 2), S = (long long)(a.N / 256) * rows * 8;
+            mx.Cq[0] = b; mx.Cs[0] = b + P;
+            if (op.out_lo) { mx.Cq[1] = b + P + S; mx.Cs[1] = b + 2 * P + S; }
+            mx.ldcq = a.N / 2;
+            mx.c_srows = rows;
+        }
+        return launch_ring_mx(mx, op.out_mx != nullptr, s);
+    }
     a.nsub = op.w_split ? (op.in_lo ? 3 : 2) : 1;
     a.a_lo_delta = op.in_lo ? static_cast<const char*>(op.in_lo) - static_cast<const char*>(op.in) : 0;
     a.R_lo = op.in2_lo; a.C_lo = op.out_lo;

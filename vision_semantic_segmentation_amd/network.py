@@ -42,6 +42,7 @@ class AvlSegOp(C.Structure):
         ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32), ("groups", C.c_int32),
         ("relu", C.c_int32), ("out_f32", C.c_int32), ("w_rows", C.c_int32), ("w_layout", C.c_int32), ("w_split", C.c_int32), ("reserved", C.c_int32),
         ("in_lo", C.c_void_p), ("in2_lo", C.c_void_p), ("out_lo", C.c_void_p),
+        ("w_mx", C.c_void_p), ("in_mx", C.c_void_p), ("out_mx", C.c_void_p),
     ]
 
 
@@ -252,13 +253,65 @@ def pack_split_rows(w, nsub):
     return torch.cat(parts, dim=2).reshape(rows, k * nsub).contiguous()
 
 
+_FP4_GRID = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0], dtype=torch.float64)
+
+
+def mx_quant_fp4(w):
+    """float64 [rows][K] (K % 256 == 0) -> (uint8 [rows][K/2], uint8 [K/256][rows][8]): OCP MX-FP4 along K as libavl_hip's
+    MX GEMM reads it (include/avl_hip.h, w_split = 2): blocks of 32, scale byte = biased exponent of the block maximum - 2
+    (the maximum lands in [4, 8) and saturates to 6), e2m1 elements rounded to nearest even, element 2i in the LOW nibble of
+    byte i -- the convention of the GPU's v_cvt_scalef32_pk_fp4_f32 (tools/micro/fp4_cvt_probe.hip)."""
+    rows, k = w.shape
+    assert k % 256 == 0
+    b = w.reshape(rows, k // 32, 32).to(torch.float64)
+    amax = b.abs().amax(dim=2)
+    e = torch.floor(torch.log2(amax.clamp_min(2.0 ** -120))).to(torch.int64) + 127           # biased exponent of amax
+    sbyte = torch.where(e >= 3, e - 2, torch.ones_like(e)).clamp(1, 254)
+    scale = torch.exp2((sbyte - 127).to(torch.float64)).unsqueeze(2)
+    mag = (b.abs() / scale).clamp_max(6.0)
+    mid = (_FP4_GRID[1:] + _FP4_GRID[:-1]) / 2
+    code = torch.bucketize(mag, mid, right=False)                  # ties go to the lower code ...
+    tie = mag == mid[(code - 0).clamp(0, 6)]                        # (bucketize(right=False): mag == mid[i] -> i)
+    code = torch.where(tie & (code % 2 == 1), code + 1, code)       # ... unless that one is odd: round half to even mantissa
+    code = code.clamp(0, 7) | ((b < 0).to(torch.int64) << 3)
+    code = code.reshape(rows, k // 2, 2)
+    packed = (code[:, :, 0] | (code[:, :, 1] << 4)).to(torch.uint8)
+    scales = sbyte.reshape(rows, k // 256, 8).permute(1, 0, 2).contiguous().to(torch.uint8)
+    return packed, scales
+
+
+def mx_dequant_fp4(packed, scales):
+    """inverse of mx_quant_fp4 (also decodes what the GPU kernels write): -> float64 [rows][K]"""
+    rows, k2 = packed.shape
+    p = packed.to(torch.int64)
+    code = torch.stack([p & 15, p >> 4], dim=2).reshape(rows, k2 * 2)
+    val = _FP4_GRID[code & 7] * torch.where((code & 8) != 0, -1.0, 1.0)
+    sc = scales.permute(1, 0, 2).reshape(rows, -1).to(torch.float64)                          # [rows][K/32]
+    return (val.reshape(rows, -1, 32) * torch.exp2(sc - 127).unsqueeze(2)).reshape(rows, k2 * 2)
+
+
+def mx_bundle_bytes(rows, c):
+    """bytes of one half (plane + scales) of an MX bundle of a [rows][c] tensor"""
+    return rows * (c // 2) + (c // 256) * rows * 8
+
+
+def pack_mx_weights(w):
+    """float64 [w_rows][K] -> (f16 hi plain rows, uint8 bundle [Q4(W lo) | scales | Q4(W hi) | scales])"""
+    hi, lo = split_f16(w)
+    ql, sl = mx_quant_fp4(lo.to(torch.float64))
+    qh, sh = mx_quant_fp4(hi.to(torch.float64))
+    return hi, torch.cat([ql.reshape(-1), sl.reshape(-1), qh.reshape(-1), sh.reshape(-1)])
+
+
 class Act(object):
     """An activation [rows][ch]: one plane of the activation type, or ("mixed" precision) two float16 planes hi + lo of the
     same shape."""
-    __slots__ = ("hi", "lo", "pool_key")
+    __slots__ = ("hi", "lo", "pool_key", "mx", "mx_valid")
 
-    def __init__(self, hi, lo=None, pool_key=None):
+    def __init__(self, hi, lo=None, pool_key=None, mx=None):
         self.hi, self.lo, self.pool_key = hi, lo, pool_key
+        self.mx = mx               # uint8 MX bundle (FP4 copies + scales of hi [and lo]) for the next MX GEMM, or None
+        self.mx_valid = False      # set by the op that fills it
 
     @property
     def shape(self):
@@ -283,6 +336,8 @@ class SegNet(object):
         self.mixed = precision == "mixed"
         self.mixed_conv1_split = self.mixed and mixed_opts.get("conv1_split", True)     # conv1 / downsample read trunk hi + lo
         self.mixed_conv2_split = self.mixed and mixed_opts.get("conv2_split", False)    # conv2 writes hi + lo, conv3 reads both
+        # correction products on the block-scaled matrix cores (MX-FP4, 4x the f16 rate) wherever shapes allow (K, N % 256)
+        self.mixed_mx = self.mixed and mixed_opts.get("mx", True)
         self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "mixed": torch.float16}[precision]
         self.avl_dtype = {"bf16": _lib.AVL_BF16, "f16": _lib.AVL_F16, "f32": _lib.AVL_F32, "mixed": _lib.AVL_F16}[precision]
         self.half = precision != "f32"              # 16-bit activations: MFMA stem / grouped-conv kernels
@@ -305,12 +360,15 @@ class SegNet(object):
             pass
 
     # -------------------------------------------------------------------------------- buffers
-    def _act(self, rows, ch, split=False):
-        """activation buffer [rows padded][ch] (split: two planes)"""
+    def _act(self, rows, ch, split=False, mx=False):
+        """activation buffer [rows padded][ch] (split: two planes; mx: plus the MX-FP4 bundle the next MX GEMM reads)"""
         prow = _round_up(rows, self.ROW_PAD)
-        key = (prow, ch, bool(split))
+        mx = bool(mx and self.mixed_mx and ch % 256 == 0)
+        key = (prow, ch, bool(split), mx)
         if self._free.get(key):
-            return self._free[key].pop()
+            a = self._free[key].pop()
+            a.mx_valid = False
+            return a
         if split:
             t = torch.zeros((2, prow, ch), dtype=self.act_dtype, device=self.device)
             a = Act(t[0], t[1], key)
@@ -318,6 +376,9 @@ class SegNet(object):
             t = torch.zeros((prow, ch), dtype=self.act_dtype, device=self.device)
             a = Act(t, None, key)
         self._keep.append(t)
+        if mx:
+            a.mx = torch.zeros(2 * mx_bundle_bytes(prow, ch), dtype=torch.uint8, device=self.device)
+            self._keep.append(a.mx)
         return a
 
     def _release(self, a):
@@ -359,7 +420,15 @@ class SegNet(object):
         wp = torch.zeros((w_rows, cin), dtype=torch.float64)
         wp[:cout] = w.reshape(cout, cin)
         in_lo = self._lo(src, src_col) if (self.mixed and read_lo) else 0
-        if self.mixed:
+        use_mx = (self.mixed_mx and isinstance(src, Act) and src.mx is not None and src.mx_valid and src_col == 0 and not out_f32
+                  and cin % 256 == 0 and cout % 256 == 0 and src.hi.shape[1] == cin)
+        w_mx = None
+        if use_mx:
+            whi, bundle = pack_mx_weights(wp)
+            wdev = self._dev(whi, torch.float16)
+            w_mx = bundle.to(self.device)
+            self._keep.append(w_mx)
+        elif self.mixed:
             wdev = self._dev(pack_split_rows(wp, 3 if in_lo else 2), torch.float16)
         else:
             wdev = self._dev(wp, self.act_dtype)
@@ -377,6 +446,11 @@ class SegNet(object):
             f.update(in2=rp, in2_ld=rld)
         if self.mixed:
             f.update(w_split=1, in_lo=in_lo, out_lo=self._lo(dst, dst_col), in2_lo=self._lo(res) if res is not None else 0)
+        if use_mx:
+            f.update(w_split=2, w_mx=w_mx.data_ptr(), in_mx=src.mx.data_ptr())
+            if isinstance(dst, Act) and dst.mx is not None and dst_col == 0 and dst.hi.shape[1] == cout:
+                f.update(out_mx=dst.mx.data_ptr())
+                dst.mx_valid = True
         self._op(name, OP_GEMM, **f)
 
     def _dwpw(self, name, src, hw, cin, w_dw, b_dw, w_pw, b_pw, dst, dst_col, dilation, padding=None):
@@ -414,6 +488,9 @@ class SegNet(object):
             f["out_lo"] = self._lo(dst, dst_col)
             if kind != OP_GCONV:
                 f["in_lo"] = self._lo(src)
+            elif isinstance(dst, Act) and dst.mx is not None and extra.get("w_layout") == 1:
+                f["out_mx"] = dst.mx.data_ptr()
+                dst.mx_valid = True
         f.update(extra)
         self._op(name, kind, **f)
 
@@ -479,7 +556,7 @@ class SegNet(object):
                     wg = w.reshape(GROUPS, cg, cg, 3, 3).permute(0, 3, 4, 2, 1).reshape(-1)   # [g][ky][kx][ci][co]
                     wg_d, layout = self._dev(wg, torch.float32), 0
                 bg_d = self._dev(b, torch.float32)
-                t2 = self._act(ohw[0] * ohw[1], width, split=self.mixed_conv2_split)
+                t2 = self._act(ohw[0] * ohw[1], width, split=self.mixed_conv2_split, mx=True)
                 self._spatial(p + ".conv2", OP_GCONV, t1, hw, width, t2, ohw, width, wg_d, bg_d, ksize=3, stride=s, pad=d, dil=d,
                               groups=GROUPS, relu=1, w_layout=layout, w_split=int(self.mixed))
                 self._release(t1)
@@ -502,7 +579,7 @@ class SegNet(object):
                     idn = x
                 # conv3 1x1 + bn3 + residual + relu
                 w, b = fold_bn(st, p + ".conv3.weight", p + ".bn3")
-                y = self._act(ohw[0] * ohw[1], cout, split=self.mixed)
+                y = self._act(ohw[0] * ohw[1], cout, split=self.mixed, mx=True)
                 self._gemm(p + ".conv3", t2, ohw, width, w, b, y, relu=True, res=idn)
                 self._release(t2)
                 if idn is not x:
