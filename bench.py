@@ -54,7 +54,7 @@ def self_launch(args):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup",
-           str(args.warmup), "--precision", args.precision]
+           str(args.warmup), "--precision", args.precision, "--mixed-opts", args.mixed_opts]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--precision", default="mixed", choices=["mixed", "bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle runs (no parity block, no cpu_baseline)")
+    ap.add_argument("--mixed-opts", default="", help="comma list of key=0|1 overrides for the mixed mode (conv2_split, mx, trunk_fp4, conv1_split)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -112,7 +113,8 @@ def main():
     sm = SemanticMapping(cfg, device=dev, logger=MyLogger("bench", quiet=True))
     sm.confusion_matrix = syn.log_confusion(5)
     state = random_state_dict(0)
-    net = SegNet(state, H, W, precision=args.precision, device=dev)
+    mixed_opts = {kv.split("=")[0]: bool(int(kv.split("=")[1])) for kv in args.mixed_opts.split(",") if kv}
+    net = SegNet(state, H, W, precision=args.precision, device=dev, **mixed_opts)
     net.image.copy_(image)                 # the frame is resident in the plan's input buffer (HBM)
     net.capture_graph()                    # the plan's ~90 launches replay as one hipGraph launch per frame
 

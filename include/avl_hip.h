@@ -235,7 +235,7 @@ typedef struct avl_seg_op {
                                 walks it (GEMM/DWPW: [n][K/64][hi 64 | lo 64], or [hi | lo | hi] when the input is
                                 split too; GCONV: 18 taps = 9 hi + 9 lo).  hi + lo carries ~22 significant bits:
                                 the MFMAs run on both parts and accumulate in fp32.                             */
-    int32_t reserved;
+    int32_t mx_flags;        /* w_split = 2 only, see below: AVL_MX_IN_LO | AVL_MX_RES_LO | AVL_MX_OUT_LO                     */
     /* split activations (w_split modes): a tensor may be stored as TWO f16 planes of identical shape and stride,
      * value = hi + lo.  NULL = the tensor is a single f16 plane.  in_lo: the GEMM / depthwise input's low plane;
      * in2_lo: the residual's; out_lo: where the low part of the result goes (the op then rounds nothing away). */
@@ -249,11 +249,20 @@ typedef struct avl_seg_op {
      *     [FP4 plane of the hi part: rows x C/2 bytes][its scales: C/256 x rows x 8 bytes][the same two for the lo part]
      * w_mx: bundle of the weights (rows = w_rows; first Q4(W lo), then Q4(W hi)); in_mx: bundle of the input (rows = in_rows);
      * out_mx (GEMM with w_split = 2, or GCONV with w_split = 1): the op also writes the bundle of its OUTPUT (rows = out_rows;
-     * the lo half only if out_lo is set), which is what the next MX GEMM reads as in_mx. */
+     * the lo half only if out_lo is set), which is what the next MX GEMM reads as in_mx.
+     * A tensor may keep its lo part ONLY as the FP4 half of its bundle (no f16 lo plane: 3 instead of 5 bytes per element
+     * for the residual trunk).  mx_flags then says so: AVL_MX_IN_LO = the input's lo part is in in_mx (in_lo NULL);
+     * AVL_MX_RES_LO = the residual's lo part is the FP4 lo half of in2_mx (in2_lo NULL; the 10 % error of FP4 applies to a
+     * term that is 2^-11 of the sum); AVL_MX_OUT_LO = write the lo half of out_mx although out_lo is NULL. */
     const void* w_mx;
     const void* in_mx;
     void* out_mx;
+    const void* in2_mx;
 } avl_seg_op;
+
+#define AVL_MX_IN_LO 1
+#define AVL_MX_RES_LO 2
+#define AVL_MX_OUT_LO 4
 
 typedef struct avl_seg_plan avl_seg_plan;
 

@@ -315,6 +315,7 @@ def _unbundle(buf, rows, c, half):
     (40000, 512, 1024, False, True, True, True, True),        # conv3-like: split residual and output, FP4 copy of the output
     (70000, 1024, 256, True, None, False, False, True),       # conv1-like: both corrections
     (300, 2048, 2048, True, False, True, True, False),        # fewer rows than one tile, single-plane residual
+    (40000, 512, 1024, "fp4", "fp4", "fp4", True, True),      # the trunk form: every lo part only as FP4 (mx_flags)
 ])
 def test_mx_gemm(case, cuda_device):
     """w_split = 2: main product on f16 hi parts, corrections Q4(W lo) x Q4(x hi) [+ Q4(W hi) x Q4(x lo)] on the block-scaled
@@ -323,6 +324,9 @@ def test_mx_gemm(case, cuda_device):
     from vision_semantic_segmentation_amd import _lib
     from vision_semantic_segmentation_amd.network import OP_GEMM, AvlSegOp, mx_dequant_fp4, mx_quant_fp4, pack_mx_weights
     M, K, N, a_split, r_split, o_split, quant_out, relu = case
+    fp4_only = a_split == "fp4"
+    if fp4_only:
+        a_split, r_split, o_split = True, True, False
     g = torch.Generator().manual_seed(M + K + N)
     Mp = (M + 255) // 256 * 256
     a64 = torch.randn((M, K), generator=g, dtype=torch.float64) * torch.exp2(torch.randint(-3, 4, (M, 1), generator=g).double())
@@ -340,7 +344,7 @@ def test_mx_gemm(case, cuda_device):
     if r_split is not None:
         r64 = torch.randn((M, N), generator=g, dtype=torch.float64)
         r_hi, r_lo = _split(r64)
-        ref = ref + r_hi.double() + (r_lo.double() if r_split else 0)
+        ref = ref + r_hi.double() + ((deq(_pad_rows(r_lo, Mp))[:M] if fp4_only else r_lo.double()) if r_split else 0)
     if relu:
         ref = torch.relu(ref)
     planes = torch.stack([_pad_rows(a_hi, Mp), _pad_rows(a_lo, Mp)]).to(cuda_device)
@@ -356,7 +360,7 @@ def test_mx_gemm(case, cuda_device):
     op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = 1, M, N, N, Mp
     op.relu, op.w_rows, op.ksize, op.stride, op.dil, op.groups = int(relu), N, 1, 1, 1, 1
     op.w_split, op.w_mx, op.in_mx = 2, wmx.data_ptr(), in_mx.data_ptr()
-    if a_split:
+    if a_split and not fp4_only:
         op.in_lo = planes[1].data_ptr()
     if o_split:
         op.out_lo = out[1].data_ptr()
@@ -365,10 +369,24 @@ def test_mx_gemm(case, cuda_device):
     if r_split is not None:
         rd = torch.stack([_pad_rows(r_hi, Mp), _pad_rows(r_lo, Mp)]).to(cuda_device)
         op.in2, op.in2_ld = rd[0].data_ptr(), N
-        if r_split:
+        if r_split and not fp4_only:
             op.in2_lo = rd[1].data_ptr()
+    if fp4_only:
+        from vision_semantic_segmentation_amd.network import AVL_MX_IN_LO, AVL_MX_OUT_LO, AVL_MX_RES_LO
+        r_mx = _bundle(r_hi, r_lo, Mp).to(cuda_device)
+        op.in2_mx, op.mx_flags = r_mx.data_ptr(), AVL_MX_IN_LO | AVL_MX_RES_LO | AVL_MX_OUT_LO
     _run_plan([op])
     got = out[0, :M].cpu().double() + (out[1, :M].cpu().double() if o_split else 0)
+    if fp4_only:
+        # value = f16 plane + FP4 lo half of the bundle: the lo part carries FP4's ~12 % error, i.e. 2^-11 * 0.12 of the value
+        v_hi, v_lo = _unbundle(out_mx.cpu(), Mp, N, 0)[2], _unbundle(out_mx.cpu(), Mp, N, 1)[2]
+        want_lo = ref - got
+        assert float((v_lo[:M] - want_lo).abs().max() / ref.abs().max()) <= 2 ** -11 * 0.3
+        assert torch.all(out[1] == 7.0)                                  # no f16 lo plane is written
+        err = float((got + v_lo[:M] - ref).abs().max() / ref.abs().max())
+        assert err <= 2 ** -11 * 0.3, "mx gemm %s: %.3e" % (case, err)
+        assert float((v_hi[:M] - got).abs().max() / ref.abs().max()) <= 0.3      # the FP4 copy of the hi plane is a 2-3 bit image of it
+        return
     err = float((got - ref).abs().max() / ref.abs().max())
     assert err <= (TOL if o_split else 2 ** -11 * 1.5), "mx gemm %s: %.3e" % (case, err)
     assert torch.all(out[0, M:] == 7.0)

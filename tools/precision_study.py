@@ -279,6 +279,36 @@ def main():
                 d["aspp.b%d.pw:a" % i] = "f32"
             report("built config, corrections in %s" % fmt, Policy("f16", **d))
             report("  + all conv1, conv2 out split (%s)" % fmt, Policy("f16", **blocks(L34 + L12, "conv2", blocks(L34 + L12, "conv1", dict(d)))))
+    if sel == "asp":
+        def blocks(layers, conv, dd):
+            for li, nb in layers:
+                for b in range(nb):
+                    dd["layer%d.%d.%s:a" % (li, b, conv)] = "f32"
+            return dd
+        L34, L12 = ((3, 6), (4, 3)), ((1, 3), (2, 4))
+        d = {":w": "mx4", ":t": "f32", ":ta": "f32", "stem": "f16", "dec": "f32", "dec:w": "mx4",
+             "aspp.b0:a": "f32", "aspp.proj:a": "f32"}
+        for i in (1, 2, 3):
+            d["aspp.b%d.dw" % i] = "f16"
+            d["aspp.b%d.pw:a" % i] = "f32"
+        d = blocks(L34 + L12, "conv2", d)
+        report("built + conv2 split everywhere", Policy("f16", **d))
+        report("  + stem weights split", Policy("f16", **dict(d, **{"stem:w": X})))
+        report("  + stem weights split + stem out exact", Policy("f16", **dict(d, **{"stem:w": X, "stem:a": "f32"})))
+        e = dict(d)
+        for i in (1, 2, 3):
+            e["aspp.b%d.dw:w" % i] = "f32"
+        report("  + aspp dw weights fp32", Policy("f16", **e))
+        e2 = dict(e)
+        for i in (1, 2, 3):
+            e2["aspp.b%d.dw:a" % i] = "f32"
+        report("  + aspp dw weights fp32 + dw out split", Policy("f16", **e2))
+        e3 = dict(e2)
+        for i in (1, 2, 3):
+            e3["aspp.b%d.dw:ta" % i] = "f32"
+        report("  + aspp dw all exact", Policy("f16", **e3))
+        report("  + aspp dw all exact + stem w split + stem out exact", Policy("f16", **dict(e3, **{"stem:w": X, "stem:a": "f32"})))
+        report("  + aspp dw out split only (weights f16)", Policy("f16", **dict(d, **{"aspp.b1.dw:a": "f32", "aspp.b2.dw:a": "f32", "aspp.b3.dw:a": "f32"})))
     print("den (max|logit|) = %.3f" % den)
 
 

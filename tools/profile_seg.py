@@ -17,10 +17,10 @@ ap.add_argument("--precision", default="bf16")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--top", type=int, default=25)
 ap.add_argument("--kind", default="")
-ap.add_argument("--conv2-split", action="store_true")
+ap.add_argument("--no-conv2-split", action="store_true")
 a = ap.parse_args()
 
-net = SegNet(random_state_dict(0), a.h, a.w, precision=a.precision, device="cuda:0", conv2_split=a.conv2_split)
+net = SegNet(random_state_dict(0), a.h, a.w, precision=a.precision, device="cuda:0", conv2_split=not a.no_conv2_split)
 img = torch.from_numpy(np.random.default_rng(1).integers(0, 256, size=(a.h, a.w, 3), dtype=np.uint8)).cuda()
 net.forward(img)
 torch.cuda.synchronize()

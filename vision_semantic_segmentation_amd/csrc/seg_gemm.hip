@@ -561,6 +561,10 @@ struct MxArgs {
     int ldcq;
     long long c_srows;
     int nmx;                    // correction passes: 1 (weights only) or 2 (input split as well)
+    const char* Rq;             // FP4 plane + scales of the residual's lo part (instead of the f16 plane g.R_lo), or NULL
+    const char* Rs;
+    int ldrq;
+    long long r_srows;
 };
 
 __device__ __forceinline__ void glds16_saddr(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
@@ -782,18 +786,28 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
             if (p.R && live) {
                 const H* rp = static_cast<const H*>(p.R) + (long long)m * p.ldr + nbase;
                 const v8 r0 = *reinterpret_cast<const v8*>(rp), r1 = *reinterpret_cast<const v8*>(rp + 8);
+                float rl[16];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { v[i] += (float)r0[i]; v[8 + i] += (float)r1[i]; }
+                for (int i = 0; i < 16; ++i) rl[i] = 0.f;
                 if (rsplit) {
-                    const H* rl = static_cast<const H*>(p.R_lo) + (long long)m * p.ldr + nbase;
-                    const v8 l0 = *reinterpret_cast<const v8*>(rl), l1 = *reinterpret_cast<const v8*>(rl + 8);
-                    // hi + lo first (exact in fp32), then the accumulator: same order as k_gemm_ring
+                    const H* rlp = static_cast<const H*>(p.R_lo) + (long long)m * p.ldr + nbase;
+                    const v8 l0 = *reinterpret_cast<const v8*>(rlp), l1 = *reinterpret_cast<const v8*>(rlp + 8);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        v[i] = acc[mi][i >> 2][i & 3] + ((float)r0[i] + (float)l0[i]);
-                        v[8 + i] = acc[mi][2 + (i >> 2)][i & 3] + ((float)r1[i] + (float)l1[i]);
-                    }
+                    for (int i = 0; i < 8; ++i) { rl[i] = (float)l0[i]; rl[8 + i] = (float)l1[i]; }
+                } else if (q.Rq) {
+                    // the lo part as FP4: 16 values = 8 bytes, one scale byte for the lane pair's 32-block
+                    typedef float v2f __attribute__((ext_vector_type(2)));
+                    const uint2 pk = *reinterpret_cast<const uint2*>(q.Rq + (long long)m * q.ldrq + nbase / 2);
+                    const unsigned sb = (unsigned char)q.Rs[((long long)(nbase >> 8) * q.r_srows + m) * 8 + ((nbase >> 5) & 7)];
+                    const float sc = __uint_as_float(sb << 23);
+#define AVL_FP4_DEC(w, sel, o) { const v2f d = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, sc, sel); rl[o] = d.x; rl[o + 1] = d.y; }
+                    AVL_FP4_DEC(pk.x, 0, 0) AVL_FP4_DEC(pk.x, 1, 2) AVL_FP4_DEC(pk.x, 2, 4) AVL_FP4_DEC(pk.x, 3, 6)
+                    AVL_FP4_DEC(pk.y, 0, 8) AVL_FP4_DEC(pk.y, 1, 10) AVL_FP4_DEC(pk.y, 2, 12) AVL_FP4_DEC(pk.y, 3, 14)
+#undef AVL_FP4_DEC
                 }
+                // hi + lo first (exact in fp32), then the accumulator: same order as k_gemm_ring
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { v[i] += (float)r0[i] + rl[i]; v[8 + i] += (float)r1[i] + rl[8 + i]; }
             }
             if (p.relu) {
 #pragma unroll
@@ -894,6 +908,10 @@ int validate_gemm(const avl_seg_op& op) {
         AVL_REQUIRE(op.in_ld == K && op.in_rows % 256 == 0 && op.in_rows >= M, "MX GEMM input must be dense rows padded to 256 (ld %d, rows %d)", op.in_ld, op.in_rows);
         AVL_REQUIRE(!op.out_f32 && op.out_ld >= N && (op.out_ld * 2) % 16 == 0, "MX GEMM output");
         AVL_REQUIRE(!op.out_mx || op.out_ld == N, "MX GEMM can only quantise a dense output (out_ld %d, N %d)", op.out_ld, N);
+        AVL_REQUIRE(!(op.mx_flags & AVL_MX_RES_LO) || (op.in2 && op.in2_mx && !op.in2_lo && op.in2_ld == N),
+                    "AVL_MX_RES_LO needs in2, in2_mx (bundle of a dense [out_rows][N] residual) and no in2_lo");
+        AVL_REQUIRE(!(op.mx_flags & AVL_MX_OUT_LO) || op.out_mx, "AVL_MX_OUT_LO without out_mx");
+        AVL_REQUIRE(!(op.mx_flags & AVL_MX_IN_LO) || !op.in_lo, "AVL_MX_IN_LO together with in_lo");
         AVL_REQUIRE((long long)op.in_rows * K * 2 < 0xffffff00LL && (long long)op.w_rows * K * 2 < 0xffffff00LL, "MX GEMM operand larger than 4 GB");
         AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.w_mx) | reinterpret_cast<uintptr_t>(op.in_mx) | reinterpret_cast<uintptr_t>(op.out_mx) |
                      reinterpret_cast<uintptr_t>(op.in_lo) | reinterpret_cast<uintptr_t>(op.in2_lo) | reinterpret_cast<uintptr_t>(op.out_lo)) % 16 == 0,
@@ -936,12 +954,19 @@ int launch_gemm(const avl_seg_op& op, hipStream_t s) {
         mx.ldaq = (int)(K / 2);
         mx.a_srows = op.in_rows;
         mx.w_srows = op.w_rows;
-        mx.nmx = op.in_lo ? 2 : 1;
+        mx.nmx = (op.in_lo || (op.mx_flags & AVL_MX_IN_LO)) ? 2 : 1;
+        if (op.mx_flags & AVL_MX_RES_LO) {
+            const char* b = static_cast<const char*>(op.in2_mx);
+            const long long rows = op.out_rows, P = rows * (a.N / 2), S = (long long)(a.N / 256) * rows * 8;
+            mx.Rq = b + P + S; mx.Rs = b + 2 * P + S;
+            mx.ldrq = a.N / 2;
+            mx.r_srows = rows;
+        }
         if (op.out_mx) {
             char* b = static_cast<char*>(op.out_mx);
             const long long rows = op.out_rows, P = rows * (a.N / 2), S = (long long)(a.N / 256) * rows * 8;
             mx.Cq[0] = b; mx.Cs[0] = b + P;
-            if (op.out_lo) { mx.Cq[1] = b + P + S; mx.Cs[1] = b + 2 * P + S; }
+            if (op.out_lo || (op.mx_flags & AVL_MX_OUT_LO)) { mx.Cq[1] = b + P + S; mx.Cs[1] = b + 2 * P + S; }
             mx.ldcq = a.N / 2;
             mx.c_srows = rows;
         }

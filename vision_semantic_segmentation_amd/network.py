@@ -40,10 +40,13 @@ class AvlSegOp(C.Structure):
         ("out_h", C.c_int32), ("out_w", C.c_int32), ("out_c", C.c_int32), ("out_ld", C.c_int32), ("out_rows", C.c_int32),
         ("in2_ld", C.c_int32),
         ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32), ("groups", C.c_int32),
-        ("relu", C.c_int32), ("out_f32", C.c_int32), ("w_rows", C.c_int32), ("w_layout", C.c_int32), ("w_split", C.c_int32), ("reserved", C.c_int32),
+        ("relu", C.c_int32), ("out_f32", C.c_int32), ("w_rows", C.c_int32), ("w_layout", C.c_int32), ("w_split", C.c_int32), ("mx_flags", C.c_int32),
         ("in_lo", C.c_void_p), ("in2_lo", C.c_void_p), ("out_lo", C.c_void_p),
-        ("w_mx", C.c_void_p), ("in_mx", C.c_void_p), ("out_mx", C.c_void_p),
+        ("w_mx", C.c_void_p), ("in_mx", C.c_void_p), ("out_mx", C.c_void_p), ("in2_mx", C.c_void_p),
     ]
+
+
+AVL_MX_IN_LO, AVL_MX_RES_LO, AVL_MX_OUT_LO = 1, 2, 4
 
 
 _vp, _i = C.c_void_p, C.c_int
@@ -306,12 +309,13 @@ def pack_mx_weights(w):
 class Act(object):
     """An activation [rows][ch]: one plane of the activation type, or ("mixed" precision) two float16 planes hi + lo of the
     same shape."""
-    __slots__ = ("hi", "lo", "pool_key", "mx", "mx_valid")
+    __slots__ = ("hi", "lo", "pool_key", "mx", "mx_valid", "lo_fp4")
 
     def __init__(self, hi, lo=None, pool_key=None, mx=None):
         self.hi, self.lo, self.pool_key = hi, lo, pool_key
         self.mx = mx               # uint8 MX bundle (FP4 copies + scales of hi [and lo]) for the next MX GEMM, or None
         self.mx_valid = False      # set by the op that fills it
+        self.lo_fp4 = False        # the lo part exists ONLY as the FP4 half of the bundle (no f16 lo plane)
 
     @property
     def shape(self):
@@ -335,9 +339,10 @@ class SegNet(object):
         # outputs and the whole decoder are stored as two f16 planes, and a GEMM runs 2 or 3 MFMA passes per K block.
         self.mixed = precision == "mixed"
         self.mixed_conv1_split = self.mixed and mixed_opts.get("conv1_split", True)     # conv1 / downsample read trunk hi + lo
-        self.mixed_conv2_split = self.mixed and mixed_opts.get("conv2_split", False)    # conv2 writes hi + lo, conv3 reads both
+        self.mixed_conv2_split = self.mixed and mixed_opts.get("conv2_split", True)     # conv2 writes hi + lo, conv3 reads both
         # correction products on the block-scaled matrix cores (MX-FP4, 4x the f16 rate) wherever shapes allow (K, N % 256)
         self.mixed_mx = self.mixed and mixed_opts.get("mx", True)
+        self.mixed_trunk_fp4 = mixed_opts.get("trunk_fp4", True)
         self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "mixed": torch.float16}[precision]
         self.avl_dtype = {"bf16": _lib.AVL_BF16, "f16": _lib.AVL_F16, "f32": _lib.AVL_F32, "mixed": _lib.AVL_F16}[precision]
         self.half = precision != "f32"              # 16-bit activations: MFMA stem / grouped-conv kernels
@@ -360,11 +365,14 @@ class SegNet(object):
             pass
 
     # -------------------------------------------------------------------------------- buffers
-    def _act(self, rows, ch, split=False, mx=False):
-        """activation buffer [rows padded][ch] (split: two planes; mx: plus the MX-FP4 bundle the next MX GEMM reads)"""
+    def _act(self, rows, ch, split=False, mx=False, lo_fp4=False):
+        """activation buffer [rows padded][ch] (split: two planes; mx: plus the MX-FP4 bundle the next MX GEMM reads;
+        lo_fp4: one f16 plane, the lo part only as FP4 in the bundle)"""
         prow = _round_up(rows, self.ROW_PAD)
         mx = bool(mx and self.mixed_mx and ch % 256 == 0)
-        key = (prow, ch, bool(split), mx)
+        lo_fp4 = bool(lo_fp4 and mx)
+        split = bool(split and not lo_fp4)
+        key = (prow, ch, bool(split), mx, lo_fp4)
         if self._free.get(key):
             a = self._free[key].pop()
             a.mx_valid = False
@@ -379,6 +387,7 @@ class SegNet(object):
         if mx:
             a.mx = torch.zeros(2 * mx_bundle_bytes(prow, ch), dtype=torch.uint8, device=self.device)
             self._keep.append(a.mx)
+        a.lo_fp4 = lo_fp4
         return a
 
     def _release(self, a):
@@ -446,11 +455,24 @@ class SegNet(object):
             f.update(in2=rp, in2_ld=rld)
         if self.mixed:
             f.update(w_split=1, in_lo=in_lo, out_lo=self._lo(dst, dst_col), in2_lo=self._lo(res) if res is not None else 0)
+        flags = 0
         if use_mx:
             f.update(w_split=2, w_mx=w_mx.data_ptr(), in_mx=src.mx.data_ptr())
+            if src.lo_fp4 and read_lo:
+                flags |= AVL_MX_IN_LO
+            if isinstance(res, Act) and res.lo_fp4:
+                f.update(in2_mx=res.mx.data_ptr())
+                flags |= AVL_MX_RES_LO
             if isinstance(dst, Act) and dst.mx is not None and dst_col == 0 and dst.hi.shape[1] == cout:
                 f.update(out_mx=dst.mx.data_ptr())
                 dst.mx_valid = True
+                if dst.lo_fp4:
+                    flags |= AVL_MX_OUT_LO
+        else:
+            for t_, what in ((src if read_lo else None, "input"), (res, "residual"), (dst, "output")):
+                if isinstance(t_, Act) and t_.lo_fp4:
+                    raise RuntimeError("%s: the %s keeps its lo part as FP4 only, which needs the MX GEMM" % (name, what))
+        f["mx_flags"] = flags
         self._op(name, OP_GEMM, **f)
 
     def _dwpw(self, name, src, hw, cin, w_dw, b_dw, w_pw, b_pw, dst, dst_col, dilation, padding=None):
@@ -579,7 +601,11 @@ class SegNet(object):
                     idn = x
                 # conv3 1x1 + bn3 + residual + relu
                 w, b = fold_bn(st, p + ".conv3.weight", p + ".bn3")
-                y = self._act(ohw[0] * ohw[1], cout, split=self.mixed, mx=True)
+                # where conv3 runs as an MX GEMM the trunk keeps its lo part only as FP4 (3 instead of 5 bytes per element move
+                # through conv3's epilogue, which is what bounds it: the 10 % error of FP4 hits a term that is 2^-11 of the sum)
+                trunk_fp4 = (self.mixed_mx and self.mixed_trunk_fp4 and t2.mx is not None and t2.mx_valid and width % 256 == 0
+                             and cout % 256 == 0 and t2.hi.shape[1] == width)
+                y = self._act(ohw[0] * ohw[1], cout, split=self.mixed, mx=True, lo_fp4=trunk_fp4)
                 self._gemm(p + ".conv3", t2, ohw, width, w, b, y, relu=True, res=idn)
                 self._release(t2)
                 if idn is not x:

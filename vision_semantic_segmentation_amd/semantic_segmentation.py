@@ -46,7 +46,7 @@ class SemanticSegmentation(object):
         key = (int(h), int(w))
         if key not in self._nets:
             net = SegNet(self.state, key[0], key[1], precision=self.precision, device=self.device, num_classes=self.num_classes,
-                         conv2_split=bool(getattr(self.cfg.MODEL, "MIXED_CONV2_SPLIT", False)))
+                         conv2_split=bool(getattr(self.cfg.MODEL, "MIXED_CONV2_SPLIT", True)))
             if getattr(self.cfg.MODEL, "HIP_GRAPH", True):
                 net.capture_graph()
             self._nets[key] = net
