@@ -151,7 +151,12 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs<HT> p) {
             if constexpr (WS != 0) {
                 float lo[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) { const float h = (float)(HT)v[r]; lo[r] = (float)(HT)(v[r] - h); v[r] = h; }   // what the planes hold
+                for (int r = 0; r < 8; ++r) {
+                    const float h = (float)(HT)v[r];
+                    lo[r] = v[r] - h;
+                    if (p.out_lo) lo[r] = (float)(HT)lo[r];        // a stored lo plane is f16: its FP4 copy is taken from what it holds
+                    v[r] = h;
+                }
                 if (p.out_lo) Vec8<HT>::store(p.out_lo + ((long long)oy * p.OW + ox) * p.out_ld + cbase, lo);
                 // FP4 copies: the window's 32 channels (the four kq lanes of this pixel) are one MX block
 #pragma unroll
@@ -202,7 +207,7 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
         char* b = static_cast<char*>(op.out_mx);
         const long long rows = op.out_rows, P = rows * (op.out_c / 2), S = (long long)(op.out_c / 256) * rows * 8;
         a.oq[0] = b; a.os[0] = b + P;
-        if (op.out_lo) { a.oq[1] = b + P + S; a.os[1] = b + 2 * P + S; }
+        if (op.out_lo || (op.mx_flags & AVL_MX_OUT_LO)) { a.oq[1] = b + P + S; a.os[1] = b + 2 * P + S; }
     }
     a.H = op.in_h; a.W = op.in_w; a.in_ld = op.in_ld; a.OH = op.out_h; a.OW = op.out_w; a.out_ld = op.out_ld; a.C = op.in_c;
     a.stride = op.stride; a.dil = op.dil;
@@ -230,6 +235,7 @@ int validate_gconv_mfma(const avl_seg_op& op) {
     AVL_REQUIRE(!op.w_split || op.dtype == AVL_F16, "split weights need AVL_F16 activations");
     AVL_REQUIRE(!op.in_lo && !op.in2_lo && (!op.out_lo || op.w_split), "grouped conv: only the output may be split, and only with w_split");
     AVL_REQUIRE(!op.out_mx || (op.w_split == 1 && op.out_c % 256 == 0 && op.out_ld == op.out_c), "grouped conv: out_mx needs w_split, channels %% 256 == 0 and a dense output");
+    AVL_REQUIRE(!(op.mx_flags & AVL_MX_OUT_LO) || (op.out_mx && !op.out_lo), "grouped conv: AVL_MX_OUT_LO needs out_mx and no out_lo");
     const int cg = op.in_c / op.groups;
     AVL_REQUIRE(cg <= 32 && 32 % cg == 0, "MFMA grouped conv needs <= 32 channels per group dividing 32 (got %d)", cg);
     int th;

@@ -774,18 +774,38 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
         const int nbase = nt * BN + wn * 64 + kq * 16;
         const bool ncol_ok = nbase + 16 <= p.N;
         const bool rsplit = p.R_lo != nullptr, csplit = p.C_lo != nullptr;
+        // the residual of row mi + 1 is requested before row mi is worked on (its loads could otherwise not move above row
+        // mi's stores, and eight dependent load -> compute -> store rounds cost more than the K loop of a short-K tile)
+        v8 nr0 = {}, nr1 = {};
+        uint2 npk = make_uint2(0u, 0u);
+        unsigned nsb = 127u;
+        auto load_res = [&](int mi) {
+            const int m = mt * BM + wm * (MI * 16) + mi * 16 + fr;
+            if (p.R && m < p.M && ncol_ok) {
+                const H* rp = static_cast<const H*>(p.R) + (long long)m * p.ldr + nbase;
+                nr0 = *reinterpret_cast<const v8*>(rp);
+                nr1 = *reinterpret_cast<const v8*>(rp + 8);
+                if (q.Rq) {       // the lo part as FP4: 16 values = 8 bytes, one scale byte for the lane pair's 32-block
+                    npk = *reinterpret_cast<const uint2*>(q.Rq + (long long)m * q.ldrq + nbase / 2);
+                    nsb = (unsigned char)q.Rs[((long long)(nbase >> 8) * q.r_srows + m) * 8 + ((nbase >> 5) & 7)];
+                }
+            }
+        };
+        load_res(0);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int m = mt * BM + wm * (MI * 16) + mi * 16 + fr;
             const bool live = m < p.M && ncol_ok;
+            const v8 r0 = nr0, r1 = nr1;
+            const uint2 pk = npk;
+            const unsigned sb = nsb;
+            if (mi + 1 < MI) load_res(mi + 1);
             float v[16];
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[nj * 4 + r] = acc[mi][nj][r];
             if (p.R && live) {
-                const H* rp = static_cast<const H*>(p.R) + (long long)m * p.ldr + nbase;
-                const v8 r0 = *reinterpret_cast<const v8*>(rp), r1 = *reinterpret_cast<const v8*>(rp + 8);
                 float rl[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) rl[i] = 0.f;
@@ -795,10 +815,7 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { rl[i] = (float)l0[i]; rl[8 + i] = (float)l1[i]; }
                 } else if (q.Rq) {
-                    // the lo part as FP4: 16 values = 8 bytes, one scale byte for the lane pair's 32-block
                     typedef float v2f __attribute__((ext_vector_type(2)));
-                    const uint2 pk = *reinterpret_cast<const uint2*>(q.Rq + (long long)m * q.ldrq + nbase / 2);
-                    const unsigned sb = (unsigned char)q.Rs[((long long)(nbase >> 8) * q.r_srows + m) * 8 + ((nbase >> 5) & 7)];
                     const float sc = __uint_as_float(sb << 23);
 #define AVL_FP4_DEC(w, sel, o) { const v2f d = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, sc, sel); rl[o] = d.x; rl[o + 1] = d.y; }
                     AVL_FP4_DEC(pk.x, 0, 0) AVL_FP4_DEC(pk.x, 1, 2) AVL_FP4_DEC(pk.x, 2, 4) AVL_FP4_DEC(pk.x, 3, 6)
@@ -815,7 +832,11 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
             }
             float hi[16], lo[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { hi[i] = (float)(H)v[i]; lo[i] = (float)(H)(v[i] - hi[i]); }      // the values the two planes hold
+            for (int i = 0; i < 16; ++i) {
+                hi[i] = (float)(H)v[i];
+                lo[i] = v[i] - hi[i];
+                if (csplit) lo[i] = (float)(H)lo[i];          // a stored lo plane is f16: its FP4 copy is taken from what it holds
+            }
             if (live) {
                 H* cp = static_cast<H*>(p.C) + (long long)m * p.ldc + nbase;
                 float a8[8], b8[8];

@@ -513,6 +513,8 @@ class SegNet(object):
             elif isinstance(dst, Act) and dst.mx is not None and extra.get("w_layout") == 1:
                 f["out_mx"] = dst.mx.data_ptr()
                 dst.mx_valid = True
+                if dst.lo_fp4:
+                    f["mx_flags"] = AVL_MX_OUT_LO
         f.update(extra)
         self._op(name, kind, **f)
 
@@ -578,7 +580,9 @@ class SegNet(object):
                     wg = w.reshape(GROUPS, cg, cg, 3, 3).permute(0, 3, 4, 2, 1).reshape(-1)   # [g][ky][kx][ci][co]
                     wg_d, layout = self._dev(wg, torch.float32), 0
                 bg_d = self._dev(b, torch.float32)
-                t2 = self._act(ohw[0] * ohw[1], width, split=self.mixed_conv2_split, mx=True)
+                # (conv3 as an MX GEMM reads the 3x3 output's lo part only through its FP4 copy: no f16 lo plane then)
+                t2_fp4 = self.mixed_conv2_split and self.mixed_trunk_fp4 and width % 256 == 0 and cout % 256 == 0 and layout == 1
+                t2 = self._act(ohw[0] * ohw[1], width, split=self.mixed_conv2_split, mx=True, lo_fp4=t2_fp4)
                 self._spatial(p + ".conv2", OP_GCONV, t1, hw, width, t2, ohw, width, wg_d, bg_d, ksize=3, stride=s, pad=d, dil=d,
                               groups=GROUPS, relu=1, w_layout=layout, w_split=int(self.mixed))
                 self._release(t1)
