@@ -256,15 +256,15 @@ def fps_with_uploads(net, sm, cam, image_host, points_host, dev, steps, warmup):
 
 
 def _gpu_us_per_frame(fn, dev, reps=40):
-    """GPU time of fn()'s kernels, back to back: the stream is first held busy (a 60 ms spin of matmuls) so that the host
+    """GPU time of fn()'s kernels, back to back: the stream is first held busy (a few ms of large fills) so that the host
     runs ahead and the launches queue up; HIP events bracket the reps on the launch stream (torch's current stream)."""
     import torch
-    a = torch.randn((4096, 4096), device=dev, dtype=torch.float16)
+    a = torch.empty(1 << 28, device=dev, dtype=torch.float32)          # 1 GiB: one fill ~0.3 ms
     fn()
     torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(30):
-        a @ a
+    for _ in range(20):
+        a.fill_(1.0)
     e0.record()
     for _ in range(reps):
         fn()

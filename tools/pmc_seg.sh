@@ -1,10 +1,12 @@
 #!/bin/bash
 # HBM-traffic and SQ counters per kernel for one segmentation forward (run on the GPU box via gpurun).
 # Separate --pmc passes (TCC has 4 slots: FETCH_SIZE costs 3, WRITE_SIZE 2), kernel-trace only.
+# usage: bash tools/pmc_seg.sh [precision]   (default mixed)  ->  gpurun_out/pmc_seg/summary.json
 export TMPDIR=/tmp
+PREC=${1:-mixed}
 OUT=gpurun_out/pmc_seg
 rm -rf $OUT; mkdir -p $OUT
-ARGS="tools/profile_seg.py --reps 1 --top 1"
+ARGS="tools/profile_seg.py --reps 1 --top 1 --precision $PREC"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/p1 -- python3 $ARGS > $OUT/p1.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/p2 -- python3 $ARGS > $OUT/p2.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $OUT/p3 -- python3 $ARGS > $OUT/p3.log 2>&1
@@ -13,8 +15,8 @@ import csv, glob, collections, json, re
 def fam(name):
     m = re.search(r"k_[a-z0-9_]+", name)
     base = m.group(0) if m else name[:30]
-    t = re.search(r"k_gemm_ring<(\d+), (\d+), (\d+), (\d+)", name) or re.search(r"k_gemm_ringILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)", name)
-    if t: base += "<%s,%s,%s,%s>" % t.groups()
+    t = re.search(r"k_gemm_ring<[^,]*, *(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)", name) or re.search(r"k_gemm_ringI[^L]*Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)", name)
+    if t and "ring_mx" not in name: base += "<%s,%s,%s,%s,probe %s,nsub %s>" % t.groups()
     return base
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
 for f in glob.glob('gpurun_out/pmc_seg/p*/**/*counter_collection.csv', recursive=True):
