@@ -599,12 +599,13 @@ __device__ __forceinline__ unsigned quantize_fp4_block(const float (&v)[16], uns
     return sbyte;
 }
 
-template <int IO>
+// MI = 8: 256 x 256 tiles; MI = 4: 128 x 256 tiles for shapes that would otherwise leave half the CUs without a tile.
+template <int IO, int MI>
 __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
     typedef f16 H;
     typedef typename Half16<H>::v8 v8;
     typedef int v8i __attribute__((ext_vector_type(8)));
-    constexpr int WM = 2, WN = 4, MI = 8, STAGES = 2;
+    constexpr int WM = 2, WN = 4, STAGES = 2;
     constexpr int NW = WM * WN, BM = WM * MI * 16, BN = WN * 64;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
     constexpr int W_REGION = STAGES * A_BYTES, S_REGION = W_REGION + STAGES * W_BYTES;      // [A tiles][W tiles][scale blocks]
@@ -663,8 +664,8 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
             for (int i = 0; i < A_INSTR; ++i) glds16_saddr(sa, a_offq[i], abase + i * NW * 1024);
 #pragma unroll
             for (int i = 0; i < W_INSTR; ++i) glds16_saddr(sw, w_offq[i], wbase + i * NW * 1024);
-            // scales: 2 KB for the activation rows (waves 0, 1), 2 KB for the weight rows (waves 2, 3)
-            if (wave < 4) {
+            // scales: BM x 8 bytes for the activation rows (waves 0, 1: one KB each), 2 KB for the weight rows (waves 2, 3)
+            if (wave < 4 && (wave >= 2 || wave * 128 < BM)) {
                 const char* ss = wave < 2 ? q.As[t] + ((long long)pmb * q.a_srows + (long long)mt * BM) * 8 + wave * 1024
                                           : q.Ws[t] + ((long long)pmb * q.w_srows + (long long)nt * BN) * 8 + (wave - 2) * 1024;
                 glds16_saddr(ss, (unsigned)lane * 16u, lds_base + S_REGION + (issued % STAGES) * S_BYTES + wave * 1024);
@@ -875,22 +876,27 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
     }
 }
 
-int launch_ring_mx(const MxArgs& a0, bool quantize_out, hipStream_t s) {
-    constexpr int LDS = 2 * (256 + 256) * 128 + 2 * 4096;
+template <int IO, int MI>
+int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
+    constexpr int BM = 2 * MI * 16, LDS = 2 * (BM + 256) * 128 + 2 * 4096;
     MxArgs a = a0;
     a.g.ntiles = a.g.N / 256;
-    const int mtiles = (a.g.M + 255) / 256;
+    const int mtiles = (a.g.M + BM - 1) / BM;
     const int total = mtiles * a.g.ntiles;
     const int grid = total < 256 ? total : 256;
-    if (quantize_out) {
-        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring_mx<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        hipLaunchKernelGGL(k_gemm_ring_mx<1>, dim3(grid), dim3(512), LDS, s, a, mtiles);
-    } else {
-        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring_mx<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        hipLaunchKernelGGL(k_gemm_ring_mx<0>, dim3(grid), dim3(512), LDS, s, a, mtiles);
-    }
+    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring_mx<IO, MI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    hipLaunchKernelGGL((k_gemm_ring_mx<IO, MI>), dim3(grid), dim3(512), LDS, s, a, mtiles);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
+}
+
+int launch_ring_mx(const MxArgs& a, bool quantize_out, hipStream_t s) {
+    // 128-row tiles when 256-row tiles would leave more than a quarter of the 256 CUs idle (or give a ragged second wave)
+    static const int force = getenv("AVL_MX_TILE") ? atoi(getenv("AVL_MX_TILE")) : 0;       // 128 / 256: experiments
+    const long long t256 = (long long)((a.g.M + 255) / 256) * (a.g.N / 256);
+    const bool small = force ? force == 128 : (t256 < 192 || (t256 > 256 && t256 < 384));
+    if (small) return quantize_out ? launch_ring_mx_t<1, 4>(a, s) : launch_ring_mx_t<0, 4>(a, s);
+    return quantize_out ? launch_ring_mx_t<1, 8>(a, s) : launch_ring_mx_t<0, 8>(a, s);
 }
 
 struct TileCfg { int bm, bn; };
