@@ -149,6 +149,17 @@ int avl_preprocess_image(const uint8_t* bgr, int h, int w, const double* K_host,
 int avl_pack_semantic_cloud(const double* pcd, const uint8_t* label, int64_t ld, int m_host, const int32_t* m_dev,
                             void* out_records, void* stream);
 
+/* ---- the planar (no-LiDAR) mode, update_map_planar (src/mapping.py:465-488) -----------------
+ * The semantic image is warped onto the grid by a homography (generate_homography, src/homography.py:22-76:
+ * cv2.warpPerspective(image, H, (Wm, Hm)), INTER_LINEAR, zero border), every cell whose warped colour matches class i and
+ * whose column is >= sep gets map[cell][i] += 1, then negative cells are clamped to 0 (:481).
+ *   Hinv_host double[9]: the INVERSE homography (grid cell (x = column, y = row) -> image pixel), row-major;
+ *   match_colour 0: the reference as written -- it compares a uint8 channel with the label NAME (:474), which is never
+ *                   true, so nothing is added and only the clamp acts;  1: R,G colour match as in update_map (Q2).
+ * OpenCV is absent here: float64 bilinear weights, round half to even (parity unpinned; oracle/planar_oracle.py). */
+int avl_planar_update(void* map, int map_dtype, int Hm, int Wm, int C, const uint8_t* image, int img_h, int img_w,
+                      const double* Hinv_host, int sep, const uint8_t* label_colors_host, int match_colour, void* stream);
+
 /* pcd_callback (src/mapping.py:172-183) without its per-point Python loop: a sensor_msgs/PointCloud2 payload
  * (`data`, n_points records of point_step bytes, FLOAT32 fields x / y / z / intensity at the given byte offsets, all
  * multiples of 4) -> out_xyzi float32[n_points][4], the layout avl_fused_frame reads.  read_points(skip_nans=True)

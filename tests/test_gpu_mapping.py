@@ -305,3 +305,50 @@ def test_pointcloud2_unpack_on_device(cuda_device):
     assert torch.equal(torch.nan_to_num(d2), torch.nan_to_num(dev_pts[:100])) and int(c2.item()) == int((~bad[:100]).sum())
     d0, c0 = a.unpack_pointcloud2_device(_pointcloud2([]))
     assert d0.shape[0] == 0 and int(c0.item()) == 0
+
+
+@pytest.mark.parametrize("match", ["reference", "colour"])
+@pytest.mark.parametrize("grid_dtype", ["f64", "f32"])
+def test_planar_mode_matches_the_restated_oracle(match, grid_dtype, cuda_device):
+    """SURVEY 8f row 2, update_map_planar (src/mapping.py:446-488; PARITY UNPINNED: OpenCV / ROS TF absent): the warp + class test +
+    clamp kernel against oracle/planar_oracle.py -- float64 arithmetic in the same order on both sides, so the grids are identical."""
+    import torch
+    from oracle import mapping_oracle as mo
+    from oracle import planar_oracle as po
+    from vision_semantic_segmentation_amd import synthetic as syn
+    from vision_semantic_segmentation_amd.camera import camera_setup_1
+    rng = np.random.default_rng(23)
+    H, W = 360, 480
+    cam = camera_setup_1().scaled(W / 1920.0, H / 1440.0)
+    # the reference discretises local y as resolution * row + BOUNDARY[1][1] (mapping.py:148-152): this boundary puts the anchor
+    # rectangle 16 .. 36 m ahead of the car and +-10 m to its sides, in view of camera 1
+    boundary = [[-4.0, 36.0], [-60.0, -20.0]]
+    sm = make_sm(boundary, 0.1, np.eye(5), True, cuda_device, grid_dtype=grid_dtype)
+    sm.planar_match = match
+    image = syn.colorize(syn.make_label_map(rng, H, W, tile=16))
+    image[100:140, 200:260] = [128, 64, 7]                    # R,G of "road" with another blue: still a match (Q2)
+    T_local_to_base = np.eye(4)
+    T_local_to_base[:3, 3] = [-1.0, 0.5, 0.0]
+    start = rng.normal(scale=2.0, size=(sm.map_height, sm.map_width, sm.map_depth)).astype(np.float64 if grid_dtype == "f64" else np.float32)
+    want = start.astype(np.float64).copy()
+    pts_img = po.planar_points_image(po.anchor_points_2(sm.map_width, sm.map_height), sm.discretize_matrix_inv, T_local_to_base,
+                                     mo.velodyne_to_baselink(), cam.P)
+    po.update_map_planar(want, image, pts_img, po.anchor_points_2(sm.map_width, sm.map_height), boundary, 0.1, mo.LABELS_NAMES,
+                         mo.LABEL_COLORS, match=match)
+    # CUDA-tensor grid, in place
+    grid_dev = torch.from_numpy(start).to(cuda_device)
+    out = sm.update_map_planar(grid_dev, image, cam, T_local_to_base=T_local_to_base)
+    assert out is grid_dev
+    got = grid_dev.cpu().numpy().astype(np.float64)
+    assert np.array_equal(got, want.astype(start.dtype).astype(np.float64))
+    if match == "colour":
+        assert (want - np.maximum(start, 0)).sum() > 1000        # the warped image does land on the grid
+    # NumPy grid (the reference's calling convention), and through mapping() with a TF stand-in
+    grid_np = start.copy()
+    assert sm.update_map_planar(grid_np, image, cam, T_local_to_base=T_local_to_base) is grid_np
+    assert np.array_equal(grid_np.astype(np.float64), got)
+    sm.depth_method = "planar"
+    sm.local_to_base_lookup = lambda stamp: T_local_to_base
+    sm.map = start
+    sm.mapping(image, None, cam)
+    assert np.array_equal(sm.map.astype(np.float64), got)

@@ -1,0 +1,55 @@
+"""oracle/planar_oracle.py (restatement of src/mapping.py:446-488 + src/homography.py:22-76; PARITY UNPINNED: OpenCV and ROS TF are
+absent and the reference holds no fixture for the mode): self-consistency of the restated pieces, and the host-side product helpers
+against it."""
+import numpy as np
+
+
+def test_homography_maps_the_anchor_points_and_warp_is_exact_for_translations():
+    from oracle import planar_oracle as po
+    src = np.array([[100, 700], [900, 650], [1500, 1000], [300, 1050.0]])
+    dst = po.anchor_points_2(2000, 2000).T
+    H = po.find_homography(src, dst)
+    p = H @ np.vstack([src.T, np.ones(4)])
+    assert np.abs(p[:2] / p[2] - dst.T).max() < 1e-9 and abs(H[2, 2] - 1.0) < 1e-15
+    img = np.random.default_rng(0).integers(0, 256, (40, 60, 3), dtype=np.uint8)
+    T = np.array([[1, 0, 3.0], [0, 1, -2.0], [0, 0, 1]])
+    w = po.warp_perspective(img, T, 60, 40)
+    assert np.array_equal(w[0:38, 3:60], img[2:40, 0:57]) and w[:, :3].max() == 0 and w[38:].max() == 0      # zero border
+
+
+def test_reference_mode_only_clamps_and_colour_mode_votes():
+    from oracle import mapping_oracle as mo
+    from oracle import planar_oracle as po
+    rng = np.random.default_rng(1)
+    mh = mw = 64
+    anchor = po.anchor_points_2(mw, mh)
+    img = np.zeros((48, 64, 3), dtype=np.uint8)
+    img[:, :32] = mo.LABEL_COLORS[0]
+    img[:, 32:] = mo.LABEL_COLORS[2]
+    pts_img = np.array([[60.0, 20.0, 8.0, 40.0], [10.0, 12.0, 40.0, 44.0]])
+    grid = rng.normal(size=(mh, mw, 5))
+    bnd, res = [[7, 17], [0, 10]], 10.0 / 64
+    a = po.update_map_planar(grid.copy(), img, pts_img, anchor, bnd, res, mo.LABELS_NAMES, mo.LABEL_COLORS)
+    assert np.array_equal(a, np.maximum(grid, 0))                      # as written: nothing added, negatives clamped
+    b = po.update_map_planar(grid.copy(), img, pts_img, anchor, bnd, res, mo.LABELS_NAMES, mo.LABEL_COLORS, match="colour")
+    d = po.update_map_planar(np.zeros_like(grid), img, pts_img, anchor, bnd, res, mo.LABELS_NAMES, mo.LABEL_COLORS, match="colour")   # the votes
+    assert np.array_equal(b, np.maximum(grid + d, 0))                  # +1 per matching class FIRST, then the clamp (:476-481)
+    assert d[:, :, [1, 3, 4]].max() == 0 and d[:, :, 0].sum() > 50 and d[:, :, 2].sum() > 50 and set(np.unique(d)) <= {0.0, 1.0}
+    sep = int((8 - bnd[0][0]) / res)
+    assert sep == 6 and d[:, :sep].max() == 0 and d[:, sep:].max() == 1    # columns left of `sep` are masked out (mapping.py:468-470)
+
+
+def test_product_host_helpers_equal_the_oracle():
+    from oracle import mapping_oracle as mo
+    from oracle import planar_oracle as po
+    from vision_semantic_segmentation_amd.mapping import find_homography, planar_points_image
+    rng = np.random.default_rng(2)
+    src, dst = rng.uniform(0, 1000, (4, 2)), po.anchor_points_2(500, 400).T
+    assert np.array_equal(find_homography(src, dst), po.find_homography(src, dst))
+    cam = mo.camera_matrices(1)
+    Tlb = np.eye(4)
+    Tlb[:3, 3] = [5.0, -1.0, 0.2]
+    D = np.array([[0.2, 0, 100.0], [0, 0.2, 900.0], [0, 0, 1.0]])
+    a = planar_points_image(dst.T, D, Tlb, mo.velodyne_to_baselink(), cam["P"])
+    b = po.planar_points_image(dst.T, D, Tlb, mo.velodyne_to_baselink(), cam["P"])
+    assert np.array_equal(a, b) and a.shape == (2, 4)

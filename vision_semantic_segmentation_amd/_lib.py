@@ -45,6 +45,7 @@ _SIGNATURES = {
     "avl_preprocess_image": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "avl_pack_semantic_cloud": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "avl_unpack_pointcloud2": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "avl_planar_update": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp]),
     "avl_render_bev_map": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "avl_render_bev_map_thresholds": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "avl_grid_box_filter": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

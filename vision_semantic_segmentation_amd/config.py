@@ -126,6 +126,9 @@ def get_cfg_defaults():
     C.MAPPING.CONFUSION_MTX = CfgNode()
     C.MAPPING.CONFUSION_MTX.LOAD_PATH = ""
     C.MAPPING.INPUT_DIR = ""
+    # build-specific: the planar (no-LiDAR) mode's class test: "reference" = as written (mapping.py:474 compares a uint8 channel
+    # with the label NAME: never true, the mode only clamps negatives), "colour" = the R,G colour match of update_map
+    C.MAPPING.PLANAR_MATCH = "reference"
     # build-specific: element type of the grid on the GPU ("f64" = the reference's, "f32")
     C.MAPPING.GRID_DTYPE = "f64"
     C.VISION_SEM_SEG = CfgNode()

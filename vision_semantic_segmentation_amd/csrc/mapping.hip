@@ -858,6 +858,72 @@ extern "C" int avl_pack_semantic_cloud(const double* pcd, const uint8_t* label, 
 }
 
 namespace {
+struct PlanarParams {
+    double hi[9];
+    unsigned char colors[AVL_MAX_MAP_CLASSES * 3];
+    int C, sep, match, img_h, img_w;
+};
+// One lane per grid cell: inverse-map the cell into the image (float64, the oracle's expression order: this file is
+// compiled with -ffp-contract=off), bilinear R and G with a zero border, class test, +1, clamp.
+template <typename MapT>
+__global__ void __launch_bounds__(kBlock) k_planar_update(MapT* __restrict__ map, int Hm, int Wm, const unsigned char* __restrict__ img,
+                                                          PlanarParams pp) {
+    const long long cell = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (cell >= (long long)Hm * Wm) return;
+    const int y = (int)(cell / Wm), x = (int)(cell % Wm);
+    MapT* row = map + cell * pp.C;
+    if (pp.match && x >= pp.sep) {
+        const double xs = (double)x, ys = (double)y;
+        const double den = pp.hi[6] * xs + pp.hi[7] * ys + pp.hi[8];
+        double sx = (pp.hi[0] * xs + pp.hi[1] * ys + pp.hi[2]) / den;
+        double sy = (pp.hi[3] * xs + pp.hi[4] * ys + pp.hi[5]) / den;
+        if (!(__builtin_isfinite(sx) && __builtin_isfinite(sy) && __builtin_fabs(sx) < 1e9 && __builtin_fabs(sy) < 1e9)) sx = sy = -10.0;
+        const double fx = __builtin_floor(sx), fy = __builtin_floor(sy);
+        const double ax = sx - fx, ay = sy - fy;
+        const long long x0 = (long long)fx, y0 = (long long)fy;
+        double acc[2] = {0.0, 0.0};
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx) {
+                const long long xx = x0 + dx, yy = y0 + dy;
+                const bool inside = xx >= 0 && xx < pp.img_w && yy >= 0 && yy < pp.img_h;
+                const double wgt = (dx ? ax : 1.0 - ax) * (dy ? ay : 1.0 - ay);
+                const long long cx = xx < 0 ? 0 : (xx >= pp.img_w ? pp.img_w - 1 : xx), cy = yy < 0 ? 0 : (yy >= pp.img_h ? pp.img_h - 1 : yy);
+                const unsigned char* px = img + 3 * (cy * pp.img_w + cx);
+                const double wv = inside ? wgt : 0.0;
+                acc[0] = acc[0] + wv * (double)px[0];
+                acc[1] = acc[1] + wv * (double)px[1];
+            }
+        const double r = __builtin_rint(acc[0]), g = __builtin_rint(acc[1]);
+        const int ri = r < 0.0 ? 0 : (r > 255.0 ? 255 : (int)r), gi = g < 0.0 ? 0 : (g > 255.0 ? 255 : (int)g);
+        for (int i = 0; i < pp.C; ++i)
+            if (pp.colors[3 * i] == ri && pp.colors[3 * i + 1] == gi) row[i] = (MapT)((double)row[i] + 1.0);
+    }
+    for (int i = 0; i < pp.C; ++i)
+        if (row[i] < (MapT)0) row[i] = (MapT)0;                       // map_local[map_local < 0] = 0 (:481)
+}
+}  // namespace
+
+extern "C" int avl_planar_update(void* map, int map_dtype, int Hm, int Wm, int C, const uint8_t* image, int img_h, int img_w,
+                                 const double* Hinv_host, int sep, const uint8_t* label_colors_host, int match_colour, void* stream) {
+    AVL_REQUIRE(map && Hm > 0 && Wm > 0 && C > 0 && C <= AVL_MAX_MAP_CLASSES, "bad grid %dx%dx%d", Hm, Wm, C);
+    AVL_REQUIRE(map_dtype == AVL_F64 || map_dtype == AVL_F32, "map dtype %d", map_dtype);
+    AVL_REQUIRE(!match_colour || (image && Hinv_host && label_colors_host && img_h > 0 && img_w > 0), "colour matching needs image, Hinv_host and label_colors_host");
+    PlanarParams pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.C = C; pp.sep = sep; pp.match = match_colour ? 1 : 0; pp.img_h = img_h; pp.img_w = img_w;
+    if (match_colour) {
+        memcpy(pp.hi, Hinv_host, sizeof(pp.hi));
+        memcpy(pp.colors, label_colors_host, 3 * C);
+    }
+    const long long n = (long long)Hm * Wm;
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    if (map_dtype == AVL_F64) hipLaunchKernelGGL(k_planar_update<double>, grid, block, 0, avl::as_stream(stream), static_cast<double*>(map), Hm, Wm, image, pp);
+    else hipLaunchKernelGGL(k_planar_update<float>, grid, block, 0, avl::as_stream(stream), static_cast<float*>(map), Hm, Wm, image, pp);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+namespace {
 // One lane per point; fields are 4-byte aligned, so each is one dword load (a point's record is usually 16-32 bytes:
 // the wave reads a contiguous 1-2 KB).  The count goes through one ballot + one atomic per wave.
 __global__ void __launch_bounds__(kBlock) k_unpack_cloud(const unsigned char* __restrict__ data, long long n, int step, int ox, int oy,

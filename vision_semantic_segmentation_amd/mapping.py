@@ -160,6 +160,8 @@ class SemanticMapping(object):
         if self.map_depth > _lib.AVL_MAX_MAP_CLASSES:
             raise ValueError("at most %d map classes are supported" % _lib.AVL_MAX_MAP_CLASSES)
         self.grid_dtype = getattr(cfg.MAPPING, "GRID_DTYPE", "f64")
+        self.planar_match = getattr(cfg.MAPPING, "PLANAR_MATCH", "reference")
+        self.local_to_base_lookup = None       # planar mode: callable(pose_time) -> 4x4 /local_map -> /base_link (the reference's TF lookup)
 
         self.position_rel = np.array([[0, 0, 0]]).T
         self.yaw_rel = 0
@@ -211,6 +213,10 @@ class SemanticMapping(object):
             [0, 0, 1],
         ]).astype(np.float64)
         self.discretize_matrix = np.linalg.inv(self.discretize_matrix_inv)
+        self.anchor_points_2 = np.array([                                          # mapping.py:160-163
+            [self.map_width, self.map_width / 2, self.map_width / 2, self.map_width],
+            [self.map_height / 4, self.map_height / 4, self.map_height * 3 / 4, self.map_height * 3 / 4],
+        ], dtype=np.float64)
 
     def set_velodyne_to_baselink(self):
         """mapping.py:165-170"""
@@ -355,8 +361,11 @@ class SemanticMapping(object):
     def mapping(self, semantic_image, pose, camera_calibration):
         """mapping.py:292-321 for the LiDAR depth methods: one fused project+vote+apply on the GPU.
         semantic_image: uint8[H,W,3] colourised labels (NumPy or a CUDA tensor)."""
-        if self.depth_method not in ["points_map", "points_raw"]:
-            raise NotImplementedError("planar (homography) mode is outside this build's hot path (SURVEY section 8f)")
+        if self.depth_method not in ["points_map", "points_raw"]:                 # mapping.py:320-321
+            img = self._as_device_u8(semantic_image)
+            self.update_map_planar(self.map_dev, img, camera_calibration)
+            self.frames_mapped += 1
+            return
         if self.pcd is None:
             return
         if self.record_inputs:                                                   # mapping.py:309-313
@@ -517,6 +526,41 @@ class SemanticMapping(object):
         map[cx, cy, :] = rows.cpu().numpy()
         return map
 
+    def update_map_planar(self, map_local, image, cam, T_local_to_base=None):
+        """mapping.py:446-488: project the semantic image onto the map plane through a 4-point homography and update the grid
+        (avl_planar_update: warp + class test + clamp in one pass over the grid).  ``map_local``: CUDA tensor [Hm,Wm,C] (updated
+        in place) or NumPy array (uploaded, updated, written back); ``image``: uint8 [H,W,3].  The reference looks the
+        /local_map -> /base_link transform up in a live ROS TF tree (:454-457); here it is ``T_local_to_base`` (4x4) or, when
+        None, ``self.local_to_base_lookup(self.pose_time)``.  ``MAPPING.PLANAR_MATCH`` picks the class test (see config.py):
+        with "reference" the warp cannot influence the result and is skipped."""
+        match = 1 if self.planar_match == "colour" else 0
+        is_np = not isinstance(map_local, torch.Tensor)
+        grid_t = torch.from_numpy(np.ascontiguousarray(map_local)).to(self.device) if is_np else map_local
+        assert grid_t.is_cuda and grid_t.is_contiguous() and tuple(grid_t.shape) == (self.map_height, self.map_width, self.map_depth)
+        img = self._as_device_u8(image)
+        hinv = None
+        if match:
+            if T_local_to_base is None:
+                if getattr(self, "local_to_base_lookup", None) is None:
+                    raise RuntimeError("update_map_planar needs T_local_to_base (the reference reads it from ROS TF): pass it or set "
+                                       "SemanticMapping.local_to_base_lookup")
+                T_local_to_base = self.local_to_base_lookup(self.pose_time)
+            pts_img = planar_points_image(self.anchor_points_2, self.discretize_matrix_inv, np.asarray(T_local_to_base, dtype=np.float64),
+                                          self.T_velodyne_to_basklink, cam.P)
+            hinv = _dbl(np.linalg.inv(find_homography(pts_img.T, self.anchor_points_2.T)))
+        sep = max(int((8 - self.map_boundary[0][0]) / self.resolution), 0)                     # :468-470
+        dt = _lib.AVL_F64 if grid_t.dtype == torch.float64 else _lib.AVL_F32
+        s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = _lib.lib().avl_planar_update(_ptr(grid_t), dt, self.map_height, self.map_width, self.map_depth, _ptr(img), int(img.shape[0]),
+                                          int(img.shape[1]), hinv, sep, self._colors_host(), match, s)
+        _lib.check(rc, "avl_planar_update")
+        if is_np:
+            map_local[...] = grid_t.cpu().numpy()
+            return map_local
+        if self._grid is not None and grid_t.data_ptr() == self._grid.map.data_ptr():
+            self._map_host = None
+        return map_local
+
     # ------------------------------------------------------------------ multi-GPU: shared global grid
     def global_map(self, group=None, dst=None, exchange_dtype=None):
         """Sum of every rank's private grid: each rank maps its own camera stream into its
@@ -623,6 +667,37 @@ def _imgmsg_to_array(msg):
     ch = 3 if msg.encoding in ("rgb8", "bgr8", "8UC3") else 1
     a = np.frombuffer(msg.data, dtype=np.uint8).reshape(msg.height, msg.step)[:, :msg.width * ch]
     return a.reshape(msg.height, msg.width, ch) if ch == 3 else a.reshape(msg.height, msg.width)
+
+
+def find_homography(pts_src, pts_dst):
+    """cv2.findHomography(pts_src, pts_dst) for the four anchor correspondences of the planar mode (homography.py:37): the exact
+    projective map by the normalised DLT, h33 = 1.  Host float64 (a 8 x 9 SVD)."""
+    src, dst = np.asarray(pts_src, dtype=np.float64), np.asarray(pts_dst, dtype=np.float64)
+
+    def normalise(p):
+        c = p.mean(axis=0)
+        s = np.sqrt(2.0) / max(np.sqrt(((p - c) ** 2).sum(axis=1)).mean(), 1e-300)
+        return (p - c) * s, np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.0]])
+    a, Ta = normalise(src)
+    b, Tb = normalise(dst)
+    A = []
+    for (x, y), (u, v) in zip(a, b):
+        A.append([-x, -y, -1, 0, 0, 0, u * x, u * y, u])
+        A.append([0, 0, 0, -x, -y, -1, v * x, v * y, v])
+    Hn = np.linalg.svd(np.array(A))[2][-1].reshape(3, 3)
+    H = np.linalg.inv(Tb) @ Hn @ Ta
+    return H / H[2, 2]
+
+
+def planar_points_image(anchor, discretize_matrix_inv, T_local_to_base, T_velodyne_to_baselink, P):
+    """mapping.py:449-463: anchor cells -> local metres (z = 0) -> velodyne -> image pixels ([2][4]); host float64."""
+    pm = np.vstack([anchor, np.ones((1, anchor.shape[1]))])
+    pl = np.matmul(discretize_matrix_inv, pm)
+    pl[2, :] = 0
+    pl = np.vstack([pl, np.ones((1, pl.shape[1]))])
+    pv = np.matmul(np.matmul(np.linalg.inv(T_velodyne_to_baselink), T_local_to_base), pl)
+    pi = np.matmul(P, pv)
+    return pi[0:2] / pi[2]
 
 
 def unpack_pointcloud2(msg):
