@@ -264,11 +264,17 @@ typedef struct avl_seg_op {
      * A tensor may keep its lo part ONLY as the FP4 half of its bundle (no f16 lo plane: 3 instead of 5 bytes per element
      * for the residual trunk).  mx_flags then says so: AVL_MX_IN_LO = the input's lo part is in in_mx (in_lo NULL);
      * AVL_MX_RES_LO = the residual's lo part is the FP4 lo half of in2_mx (in2_lo NULL; the 10 % error of FP4 applies to a
-     * term that is 2^-11 of the sum); AVL_MX_OUT_LO = write the lo half of out_mx although out_lo is NULL. */
+     * term that is 2^-11 of the sum); AVL_MX_OUT_LO = write the lo half of out_mx although out_lo is NULL.
+     * A SECOND input (GEMM, w_split = 2): in3 [rows][in3_c] (row stride in3_ld, bundle in3_mx, same rows as `in`) is appended
+     * along K -- out = W[:, :in_c] . in + W[:, in_c:] . in3: a Bottleneck's conv3 and its downsample 1x1 (stride 1) in ONE
+     * product, the identity tensor never exists.  `weight` / `w_mx` then hold the concatenated [w_rows][in_c + in3_c] matrix. */
     const void* w_mx;
     const void* in_mx;
     void* out_mx;
     const void* in2_mx;
+    const void* in3;
+    const void* in3_mx;
+    int32_t in3_c, in3_ld;
 } avl_seg_op;
 
 #define AVL_MX_IN_LO 1

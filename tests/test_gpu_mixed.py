@@ -431,3 +431,51 @@ def test_grouped_conv_writes_the_mx_bundle(case, cuda_device):
         q_ref, s_ref = mx_quant_fp4(dst[half, :M].cpu().double())
         from vision_semantic_segmentation_amd.network import mx_dequant_fp4
         assert torch.equal(s_dev[:, :M], s_ref) and torch.equal(v_dev[:M], mx_dequant_fp4(q_ref, s_ref)), "plane %d" % half
+
+
+def test_mx_gemm_with_a_second_input_along_k(cuda_device):
+    """conv3 + stride-1 downsample as ONE MX GEMM: out = relu(W3 . t2 + Wd . x + b3 + bd), both inputs with FP4-only lo parts
+    (in3 / in3_mx of include/avl_hip.h).  Reference: float64 on the operands the kernel is given."""
+    import torch
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import (AVL_MX_IN_LO, AVL_MX_OUT_LO, OP_GEMM, AvlSegOp, mx_bundle_bytes, mx_dequant_fp4,
+                                                          mx_quant_fp4, pack_mx_weights)
+    M, K1, K2, N = 33000, 512, 256, 1024
+    g = torch.Generator().manual_seed(7)
+    Mp = (M + 255) // 256 * 256
+    deq = lambda t: mx_dequant_fp4(*mx_quant_fp4(t.double()))            # noqa: E731
+    ins = []
+    for K in (K1, K2):
+        a64 = torch.randn((M, K), generator=g, dtype=torch.float64)
+        hi, lo = _split(a64)
+        ins.append((hi, lo))
+    w64 = torch.randn((N, K1 + K2), generator=g, dtype=torch.float64) / (K1 + K2) ** 0.5
+    w_hi16, wbundle = pack_mx_weights(w64)
+    w_hi, w_lo = _split(w64)
+    b = torch.randn(N, generator=g)
+    ref = b.double().unsqueeze(0).repeat(M, 1)
+    k0 = 0
+    for (hi, lo), K in zip(ins, (K1, K2)):
+        wh, wl = w_hi[:, k0:k0 + K], w_lo[:, k0:k0 + K]
+        ref = ref + hi.double() @ wh.double().t() + deq(_pad_rows(hi, Mp))[:M] @ deq(wl).t() + deq(_pad_rows(lo, Mp))[:M] @ deq(wh).t()
+        k0 += K
+    ref = torch.relu(ref)
+    dev = [(_pad_rows(hi, Mp).to(cuda_device), _bundle(hi, lo, Mp).to(cuda_device)) for hi, lo in ins]
+    wd, wmx, bd = w_hi16.to(cuda_device), wbundle.to(cuda_device), b.to(cuda_device)
+    out = torch.full((Mp, N), 7.0, dtype=torch.float16, device=cuda_device)
+    out_mx = torch.zeros(2 * mx_bundle_bytes(Mp, N), dtype=torch.uint8, device=cuda_device)
+    op = AvlSegOp()
+    op.kind, op.dtype = OP_GEMM, _lib.AVL_F16
+    op.in_, op.out, op.weight, op.bias = dev[0][0].data_ptr(), out.data_ptr(), wd.data_ptr(), bd.data_ptr()
+    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = 1, M, K1, K1, Mp
+    op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = 1, M, N, N, Mp
+    op.relu, op.w_rows, op.ksize, op.stride, op.dil, op.groups = 1, N, 1, 1, 1, 1
+    op.w_split, op.w_mx, op.in_mx, op.out_mx = 2, wmx.data_ptr(), dev[0][1].data_ptr(), out_mx.data_ptr()
+    op.in3, op.in3_mx, op.in3_c, op.in3_ld = dev[1][0].data_ptr(), dev[1][1].data_ptr(), K2, K2
+    op.mx_flags = AVL_MX_IN_LO | AVL_MX_OUT_LO
+    _run_plan([op])
+    v_lo = _unbundle(out_mx.cpu(), Mp, N, 1)[2]
+    got = out[:M].cpu().double() + v_lo[:M]
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= 2 ** -11 * 0.3, "mx gemm with a second input: %.3e" % err
+    assert torch.all(out[M:] == 7.0)

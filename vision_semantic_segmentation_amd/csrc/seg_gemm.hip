@@ -565,6 +565,13 @@ struct MxArgs {
     const char* Rs;
     int ldrq;
     long long r_srows;
+    // second input appended along K (conv3 + downsample in one product): macro-blocks >= nmb1 read it
+    int nmb1;
+    const void* A2;
+    int lda2, ldaq2;
+    const char* Aq2[2];
+    const char* As2[2];
+    long long a_srows2;
 };
 
 __device__ __forceinline__ void glds16_saddr(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
@@ -628,15 +635,14 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
     const int nsub = 4 + q.nmx;                // sub-steps per macro-block: 4 f16 + the FP4 corrections
     const unsigned lds_base = lds_addr(lds);
 
-    // ---- producer: per-lane byte offsets inside a tile (SGPR tile base + VGPR offset addressing)
+    // ---- producer: SGPR tile base + VGPR offset addressing.  DMA instruction i of this wave covers rows (i * NW + wave) * 8 + srow:
+    // the (i, wave) part is uniform and goes into the scalar base, the lane keeps srow * row_bytes + its swizzled chunk
+    // ((r & 7) == srow); the weight swizzle key mixes uniform and lane bits, so those offsets stay per instruction.
     const int srow = lane >> 3, schunk = lane & 7;
-    unsigned a_off16[A_INSTR], a_offq[A_INSTR], w_off16[W_INSTR], w_offq[W_INSTR];
-#pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-        const int r = (i * NW + wave) * 8 + srow;
-        a_off16[i] = (unsigned)r * (unsigned)(p.lda * 2) + ((schunk ^ (r & 7)) << 4);
-        a_offq[i] = (unsigned)r * (unsigned)q.ldaq + ((schunk ^ (r & 7)) << 4);
-    }
+    const unsigned ct = (unsigned)((schunk ^ srow) << 4);
+    const unsigned a_lane16 = (unsigned)srow * (unsigned)(p.lda * 2) + ct, a_laneq = (unsigned)srow * (unsigned)q.ldaq + ct;
+    const unsigned a_lane16_2 = (unsigned)srow * (unsigned)(q.lda2 * 2) + ct, a_laneq_2 = (unsigned)srow * (unsigned)q.ldaq2 + ct;
+    unsigned w_off16[W_INSTR], w_offq[W_INSTR];
 #pragma unroll
     for (int i = 0; i < W_INSTR; ++i) {
         const int r = (i * NW + wave) * 8 + srow;
@@ -649,24 +655,32 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
         const int nt = pt % p.ntiles, mt = pt / p.ntiles;
         const unsigned abase = lds_base + (issued % STAGES) * A_BYTES + wave * 1024;
         const unsigned wbase = lds_base + W_REGION + (issued % STAGES) * W_BYTES + wave * 1024;
+        const bool second = pmb >= q.nmb1;                     // which input this K macro-block comes from
+        const int mbl = second ? pmb - q.nmb1 : pmb;
         if (pj < 4) {
-            const char* sa = static_cast<const char*>(p.A) + (long long)mt * BM * p.lda * 2 + (long long)(pmb * 4 + pj) * 128;
+            const long long rowb = second ? (long long)q.lda2 * 2 : (long long)p.lda * 2;
+            const char* sa = static_cast<const char*>(second ? q.A2 : p.A) + ((long long)mt * BM + wave * 8) * rowb + (long long)(mbl * 4 + pj) * 128;
             const char* sw = static_cast<const char*>(p.W) + (long long)nt * BN * p.K * 2 + (long long)(pmb * 4 + pj) * 128;
+            const unsigned al = second ? a_lane16_2 : a_lane16;
 #pragma unroll
-            for (int i = 0; i < A_INSTR; ++i) glds16_saddr(sa, a_off16[i], abase + i * NW * 1024);
+            for (int i = 0; i < A_INSTR; ++i) glds16_saddr(sa + (long long)i * (NW * 8) * rowb, al, abase + i * NW * 1024);
 #pragma unroll
             for (int i = 0; i < W_INSTR; ++i) glds16_saddr(sw, w_off16[i], wbase + i * NW * 1024);
         } else {
             const int t = pj - 4;
-            const char* sa = q.Aq[t] + (long long)mt * BM * q.ldaq + (long long)pmb * 128;
+            const long long rowb = second ? q.ldaq2 : q.ldaq;
+            const char* sa = (second ? q.Aq2[t] : q.Aq[t]) + ((long long)mt * BM + wave * 8) * rowb + (long long)mbl * 128;
             const char* sw = q.Wq[t] + (long long)nt * BN * (p.K / 2) + (long long)pmb * 128;
+            const unsigned al = second ? a_laneq_2 : a_laneq;
 #pragma unroll
-            for (int i = 0; i < A_INSTR; ++i) glds16_saddr(sa, a_offq[i], abase + i * NW * 1024);
+            for (int i = 0; i < A_INSTR; ++i) glds16_saddr(sa + (long long)i * (NW * 8) * rowb, al, abase + i * NW * 1024);
 #pragma unroll
             for (int i = 0; i < W_INSTR; ++i) glds16_saddr(sw, w_offq[i], wbase + i * NW * 1024);
             // scales: BM x 8 bytes for the activation rows (waves 0, 1: one KB each), 2 KB for the weight rows (waves 2, 3)
             if (wave < 4 && (wave >= 2 || wave * 128 < BM)) {
-                const char* ss = wave < 2 ? q.As[t] + ((long long)pmb * q.a_srows + (long long)mt * BM) * 8 + wave * 1024
+                const char* as = second ? q.As2[t] + ((long long)mbl * q.a_srows2 + (long long)mt * BM) * 8
+                                        : q.As[t] + ((long long)mbl * q.a_srows + (long long)mt * BM) * 8;
+                const char* ss = wave < 2 ? as + wave * 1024
                                           : q.Ws[t] + ((long long)pmb * q.w_srows + (long long)nt * BN) * 8 + (wave - 2) * 1024;
                 glds16_saddr(ss, (unsigned)lane * 16u, lds_base + S_REGION + (issued % STAGES) * S_BYTES + wave * 1024);
             }
@@ -939,6 +953,12 @@ int validate_gemm(const avl_seg_op& op) {
                     "AVL_MX_RES_LO needs in2, in2_mx (bundle of a dense [out_rows][N] residual) and no in2_lo");
         AVL_REQUIRE(!(op.mx_flags & AVL_MX_OUT_LO) || op.out_mx, "AVL_MX_OUT_LO without out_mx");
         AVL_REQUIRE(!(op.mx_flags & AVL_MX_IN_LO) || !op.in_lo, "AVL_MX_IN_LO together with in_lo");
+        if (op.in3) {
+            AVL_REQUIRE(op.in3_mx && op.in3_c > 0 && op.in3_c % 256 == 0 && op.in3_ld >= op.in3_c && (op.in3_ld * 2) % 16 == 0,
+                        "second GEMM input: in3_mx, in3_c %d (multiple of 256), in3_ld %d", op.in3_c, op.in3_ld);
+            AVL_REQUIRE(!op.in_lo || (op.mx_flags & AVL_MX_IN_LO), "a second GEMM input needs both inputs' lo parts in their bundles (AVL_MX_IN_LO) or none");
+            AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.in3) | reinterpret_cast<uintptr_t>(op.in3_mx)) % 16 == 0, "second GEMM input must be 16-byte aligned");
+        }
         AVL_REQUIRE((long long)op.in_rows * K * 2 < 0xffffff00LL && (long long)op.w_rows * K * 2 < 0xffffff00LL, "MX GEMM operand larger than 4 GB");
         AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.w_mx) | reinterpret_cast<uintptr_t>(op.in_mx) | reinterpret_cast<uintptr_t>(op.out_mx) |
                      reinterpret_cast<uintptr_t>(op.in_lo) | reinterpret_cast<uintptr_t>(op.in2_lo) | reinterpret_cast<uintptr_t>(op.out_lo)) % 16 == 0,
@@ -970,15 +990,30 @@ int launch_gemm(const avl_seg_op& op, hipStream_t s) {
         a.a_lo_delta = 0;
         a.R_lo = op.in2_lo; a.C_lo = op.out_lo;
         mx.g = a;
-        const long long K = a.K, kb = K / 256;
-        auto bundle = [&](const void* base, long long rows, const char** plane, const char** scales) {
+        // (with a second input appended along K: K1 = op.in_c comes from `in`, the rest from in3; weights span the whole K)
+        const long long K1 = op.in_c, K2 = op.in3 ? op.in3_c : 0;
+        auto abundle = [&](const void* base, long long rows, long long kk, const char** plane, const char** scales) {
             const char* b = static_cast<const char*>(base);
-            const long long P = rows * (K / 2), S = kb * rows * 8;
+            const long long P = rows * (kk / 2), S = (kk / 256) * rows * 8;
             plane[0] = b; scales[0] = b + P; plane[1] = b + P + S; scales[1] = b + 2 * P + S;
         };
-        bundle(op.in_mx, op.in_rows, mx.Aq, mx.As);
-        bundle(op.w_mx, op.w_rows, mx.Wq, mx.Ws);
-        mx.ldaq = (int)(K / 2);
+        abundle(op.in_mx, op.in_rows, K1, mx.Aq, mx.As);
+        mx.nmb1 = (int)(K1 / 256);
+        mx.lda2 = mx.g.lda; mx.ldaq2 = (int)(K1 / 2);
+        if (K2) {
+            a.K = (int)(K1 + K2);
+            mx.g.K = a.K;
+            mx.A2 = op.in3; mx.lda2 = op.in3_ld; mx.ldaq2 = (int)(K2 / 2);
+            abundle(op.in3_mx, op.in_rows, K2, mx.Aq2, mx.As2);
+            mx.a_srows2 = op.in_rows;
+        }
+        {
+            const long long KT = K1 + K2;
+            const char* b = static_cast<const char*>(op.w_mx);
+            const long long P = (long long)op.w_rows * (KT / 2), S = (KT / 256) * op.w_rows * 8;
+            mx.Wq[0] = b; mx.Ws[0] = b + P; mx.Wq[1] = b + P + S; mx.Ws[1] = b + 2 * P + S;
+        }
+        mx.ldaq = (int)(K1 / 2);
         mx.a_srows = op.in_rows;
         mx.w_srows = op.w_rows;
         mx.nmx = (op.in_lo || (op.mx_flags & AVL_MX_IN_LO)) ? 2 : 1;

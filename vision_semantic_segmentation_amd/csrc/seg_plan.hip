@@ -44,8 +44,9 @@ void work(const avl_seg_op& op, double& flops, double& bytes) {
             bytes = in_pix * 3 + out_pix * 64 * es;
             break;
         case AVL_OP_GEMM:
-            flops = 2.0 * out_pix * op.out_c * op.in_c;
-            bytes += (double)op.out_c * op.in_c * es + (op.in2 ? out_pix * op.out_c * es : 0.0);
+            flops = 2.0 * out_pix * op.out_c * (op.in_c + (op.in3 ? op.in3_c : 0));
+            bytes += (double)op.out_c * (op.in_c + (op.in3 ? op.in3_c : 0)) * es + (op.in2 ? out_pix * op.out_c * es : 0.0) +
+                     (op.in3 ? in_pix * op.in3_c * es : 0.0);
             if (op.out_f32) bytes += out_pix * op.out_c * (4 - es);
             break;
         case AVL_OP_GCONV:

@@ -43,6 +43,7 @@ class AvlSegOp(C.Structure):
         ("relu", C.c_int32), ("out_f32", C.c_int32), ("w_rows", C.c_int32), ("w_layout", C.c_int32), ("w_split", C.c_int32), ("mx_flags", C.c_int32),
         ("in_lo", C.c_void_p), ("in2_lo", C.c_void_p), ("out_lo", C.c_void_p),
         ("w_mx", C.c_void_p), ("in_mx", C.c_void_p), ("out_mx", C.c_void_p), ("in2_mx", C.c_void_p),
+        ("in3", C.c_void_p), ("in3_mx", C.c_void_p), ("in3_c", C.c_int32), ("in3_ld", C.c_int32),
     ]
 
 
@@ -343,6 +344,7 @@ class SegNet(object):
         # correction products on the block-scaled matrix cores (MX-FP4, 4x the f16 rate) wherever shapes allow (K, N % 256)
         self.mixed_mx = self.mixed and mixed_opts.get("mx", True)
         self.mixed_trunk_fp4 = mixed_opts.get("trunk_fp4", True)
+        self.mixed_fuse_ds = mixed_opts.get("fuse_ds", True)     # stride-1 downsample folded into conv3 (second input along K)
         self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "mixed": torch.float16}[precision]
         self.avl_dtype = {"bf16": _lib.AVL_BF16, "f16": _lib.AVL_F16, "f32": _lib.AVL_F32, "mixed": _lib.AVL_F16}[precision]
         self.half = precision != "f32"              # 16-bit activations: MFMA stem / grouped-conv kernels
@@ -420,7 +422,7 @@ class SegNet(object):
         return 0 if (not isinstance(a, Act) or a.lo is None) else a.lo.data_ptr() + col * a.lo.element_size()
 
     def _gemm(self, name, src, hw, cin, w, b, dst, dst_col=0, relu=True, res=None, out_f32=False, src_col=0, bias_dev=None,
-              read_lo=True):
+              read_lo=True, src2=None, w2=None, b2=None):
         """1x1 conv.  w float64 [cout][cin] (BN folded), b float64 [cout].  "mixed": weights become f16 pairs; the low
         plane of `src` is read if it has one (unless read_lo = False), `res` and `dst` are used with all the planes they have."""
         h, wd = hw
@@ -428,9 +430,16 @@ class SegNet(object):
         w_rows = _round_up(cout, 256)
         wp = torch.zeros((w_rows, cin), dtype=torch.float64)
         wp[:cout] = w.reshape(cout, cin)
+        if src2 is not None:          # a second input appended along K (MX GEMM only): conv3 + downsample in one product
+            cin2 = w2.shape[1]
+            wp2 = torch.zeros((w_rows, cin2), dtype=torch.float64)
+            wp2[:cout] = w2.reshape(cout, cin2)
+            wp = torch.cat([wp, wp2], dim=1)
+            b = b + b2
         in_lo = self._lo(src, src_col) if (self.mixed and read_lo) else 0
         use_mx = (self.mixed_mx and isinstance(src, Act) and src.mx is not None and src.mx_valid and src_col == 0 and not out_f32
                   and cin % 256 == 0 and cout % 256 == 0 and src.hi.shape[1] == cin)
+        assert src2 is None or use_mx, "%s: a second input needs the MX GEMM" % name
         w_mx = None
         if use_mx:
             whi, bundle = pack_mx_weights(wp)
@@ -460,6 +469,9 @@ class SegNet(object):
             f.update(w_split=2, w_mx=w_mx.data_ptr(), in_mx=src.mx.data_ptr())
             if src.lo_fp4 and read_lo:
                 flags |= AVL_MX_IN_LO
+            if src2 is not None:
+                assert src2.mx_valid and src2.lo_fp4 == src.lo_fp4 and src2.lo is None and src.lo is None
+                f.update(in3=src2.hi.data_ptr(), in3_mx=src2.mx.data_ptr(), in3_c=src2.hi.shape[1], in3_ld=src2.hi.shape[1])
             if isinstance(res, Act) and res.lo_fp4:
                 f.update(in2_mx=res.mx.data_ptr())
                 flags |= AVL_MX_RES_LO
@@ -586,8 +598,14 @@ class SegNet(object):
                 self._spatial(p + ".conv2", OP_GCONV, t1, hw, width, t2, ohw, width, wg_d, bg_d, ksize=3, stride=s, pad=d, dil=d,
                               groups=GROUPS, relu=1, w_layout=layout, w_split=int(self.mixed))
                 self._release(t1)
-                # identity / downsample
-                if (p + ".downsample.0.weight") in st:
+                # identity / downsample.  Stride-1 downsamples (layer3.0, layer4.0) whose input and the 3x3 output both carry MX
+                # bundles are folded into conv3 as a second input along K: the identity tensor never exists
+                fuse_ds = ((p + ".downsample.0.weight") in st and s == 1 and self.mixed_mx and self.mixed_fuse_ds and x.mx is not None
+                           and x.mx_valid and x.hi.shape[1] == cin and cin % 256 == 0 and t2.mx is not None and t2.mx_valid
+                           and width % 256 == 0 and cout % 256 == 0 and t2.lo_fp4 and x.lo_fp4)
+                if fuse_ds:
+                    idn = None
+                elif (p + ".downsample.0.weight") in st:
                     w, b = fold_bn(st, p + ".downsample.0.weight", p + ".downsample.1")
                     src = x
                     if s != 1:
@@ -610,9 +628,13 @@ class SegNet(object):
                 trunk_fp4 = (self.mixed_mx and self.mixed_trunk_fp4 and t2.mx is not None and t2.mx_valid and width % 256 == 0
                              and cout % 256 == 0 and t2.hi.shape[1] == width)
                 y = self._act(ohw[0] * ohw[1], cout, split=self.mixed, mx=True, lo_fp4=trunk_fp4)
-                self._gemm(p + ".conv3", t2, ohw, width, w, b, y, relu=True, res=idn)
+                if fuse_ds:
+                    wd_, bd_ = fold_bn(st, p + ".downsample.0.weight", p + ".downsample.1")
+                    self._gemm(p + ".conv3+downsample", t2, ohw, width, w, b, y, relu=True, src2=x, w2=wd_.reshape(cout, cin), b2=bd_)
+                else:
+                    self._gemm(p + ".conv3", t2, ohw, width, w, b, y, relu=True, res=idn)
                 self._release(t2)
-                if idn is not x:
+                if idn is not x and idn is not None:
                     self._release(idn)
                 if x is not low:              # layer1's output stays alive for the decoder
                     self._release(x)
