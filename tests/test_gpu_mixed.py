@@ -479,3 +479,44 @@ def test_mx_gemm_with_a_second_input_along_k(cuda_device):
     err = float((got - ref).abs().max() / ref.abs().max())
     assert err <= 2 ** -11 * 0.3, "mx gemm with a second input: %.3e" % err
     assert torch.all(out[M:] == 7.0)
+
+
+@pytest.mark.parametrize("case", [(37, 53, 256, 1, 0), (20, 31, 512, 1, 0)])
+def test_split_depthwise_writes_the_mx_bundle(case, cuda_device):
+    """The mixed decoder's depthwise conv feeding an MX GEMM: f16 hi plane + FP4 copies of hi and of the lo part (which is kept as
+    FP4 only, AVL_MX_OUT_LO)."""
+    import torch
+    import torch.nn.functional as F
+    from test_gpu_ops import _from_rows, _nhwc_rows, _spatial_op
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import AVL_MX_OUT_LO, OP_DWCONV, mx_bundle_bytes, mx_dequant_fp4, mx_quant_fp4
+    H, W, Cc, d, pad = case
+    g = torch.Generator().manual_seed(H * 1000 + W + d)
+    x_hi, x_lo = _split(torch.randn((1, Cc, H, W), generator=g, dtype=torch.float64))
+    w = torch.randn((Cc, 1, 3, 3), generator=g) * 0.3
+    b = torch.randn(Cc, generator=g) * 0.1
+    OH, OW = H + 2 * pad - 2 * d, W + 2 * pad - 2 * d
+    ref = F.relu(F.conv2d(x_hi.double() + x_lo.double(), w.double(), b.double(), padding=pad, dilation=d, groups=Cc))
+    src = torch.stack([_nhwc_rows(x_hi), _nhwc_rows(x_lo)]).to(cuda_device)
+    rows = (OH * OW + 255) // 256 * 256
+    dst = torch.full((2, rows, Cc), 7.0, dtype=torch.float16, device=cuda_device)
+    mx = torch.full((2 * mx_bundle_bytes(rows, Cc),), 0xEE, dtype=torch.uint8, device=cuda_device)
+    wd, bd = w.reshape(Cc, 9).t().contiguous().reshape(-1).to(cuda_device), b.to(cuda_device)
+    zero = torch.zeros(64, dtype=torch.uint8, device=cuda_device)
+    _run_plan([_spatial_op(OP_DWCONV, _lib.AVL_F16, src[0], (H, W), Cc, dst[0], (OH, OW), Cc, weight=wd.data_ptr(), bias=bd.data_ptr(),
+                           in2=zero.data_ptr(), ksize=3, stride=1, pad=pad, dil=d, groups=Cc, relu=1, in_lo=src[1].data_ptr(),
+                           out_mx=mx.data_ptr(), mx_flags=AVL_MX_OUT_LO)])
+    M = OH * OW
+    hi = dst[0, :M].cpu().double()
+    assert torch.all(dst[1] == 7.0)                                           # no f16 lo plane
+    q_dev, s_dev, v_hi = _unbundle(mx.cpu(), rows, Cc, 0)
+    q_ref, s_ref = mx_quant_fp4(hi)
+    assert torch.equal(s_dev[:, :M], s_ref) and torch.equal(v_hi[:M], mx_dequant_fp4(q_ref, s_ref))
+    v_lo = _unbundle(mx.cpu(), rows, Cc, 1)[2][:M]
+    want = _from_rows_inv(ref, M, Cc)
+    assert float((hi + v_lo - want).abs().max() / want.abs().max()) <= 2 ** -11 * 0.3
+
+
+def _from_rows_inv(x, m, c):
+    """[1,C,H,W] -> [H*W][C]"""
+    return x[0].permute(1, 2, 0).reshape(m, c)

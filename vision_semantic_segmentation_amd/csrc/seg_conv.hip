@@ -160,10 +160,19 @@ struct DwGeom {
 
 // SPLIT ("mixed" precision, f16): input and output are two planes hi + lo (in_lo / out_lo, same offsets); the taps are
 // summed to fp32 (exact) and go through the fp32 FMA chain with the fp32 weights, nothing is rounded away at the output.
+// MX-FP4 copies of an output (include/avl_hip.h, "MX bundle"): planes [rows][C/2] bytes + E8M0 scales [C/256][rows][8]
+struct MxOut {
+    char* q[2];          // FP4 plane of the hi part / of the lo part (NULL = not written)
+    char* s[2];
+    long long srows;
+    int ldq;
+};
+
 template <typename T, bool SPLIT = false>
 __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, const float* __restrict__ w,
                                                     const float* __restrict__ bias, T* __restrict__ out, const T* __restrict__ zero,
-                                                    DwGeom g, const T* __restrict__ in_lo = nullptr, T* __restrict__ out_lo = nullptr) {
+                                                    DwGeom g, const T* __restrict__ in_lo = nullptr, T* __restrict__ out_lo = nullptr,
+                                                    MxOut mx = MxOut()) {
     const int cgrp = blockIdx.x % g.cgroups, ub = blockIdx.x / g.cgroups;
     const int chunk = threadIdx.x % g.nchunk, cl = threadIdx.x / g.nchunk;
     if (cl >= g.cl) return;
@@ -291,9 +300,40 @@ __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, c
             }
             Vec8<T>::store(out + ((long long)oy * g.OW + ox) * g.out_ld + c8 * 8, acc);
             if constexpr (SPLIT) {
+                float hi8[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] -= to_f32(from_f32<T>(acc[i]));
-                Vec8<T>::store(out_lo + ((long long)oy * g.OW + ox) * g.out_ld + c8 * 8, acc);
+                for (int i = 0; i < 8; ++i) { hi8[i] = to_f32(from_f32<T>(acc[i])); acc[i] -= hi8[i]; }
+                if (out_lo) {
+                    Vec8<T>::store(out_lo + ((long long)oy * g.OW + ox) * g.out_ld + c8 * 8, acc);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = to_f32(from_f32<T>(acc[i]));        // the FP4 copy is taken from what the plane holds
+                }
+                // FP4 copies for the MX GEMM that follows: four consecutive lanes (channel chunks of one pixel) form a 32-block
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    if (mx.q[pl] == nullptr) continue;
+                    const float* src = pl == 0 ? hi8 : acc;
+                    float amax = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(src[i]));
+                    amax = fmaxf(amax, __shfl_xor(amax, 1));
+                    amax = fmaxf(amax, __shfl_xor(amax, 2));
+                    const unsigned e = __float_as_uint(amax) >> 23;
+                    const unsigned sbyte = e >= 3u ? e - 2u : 1u;
+                    const float scale = __uint_as_float(sbyte << 23);
+                    unsigned pk = 0u;
+                    pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[0], src[1], scale, 0);
+                    pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[2], src[3], scale, 1);
+                    pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[4], src[5], scale, 2);
+                    pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[6], src[7], scale, 3);
+                    const long long pix = (long long)oy * g.OW + ox;
+                    // the block's 16 bytes leave through its first lane as ONE store (4-byte stores from four lanes cost more)
+                    const unsigned p1 = __shfl_down(pk, 1), p2 = __shfl_down(pk, 2), p3 = __shfl_down(pk, 3);
+                    if ((c8 & 3) == 0) {
+                        *reinterpret_cast<uint4*>(mx.q[pl] + pix * mx.ldq + c8 * 4) = make_uint4(pk, p1, p2, p3);
+                        mx.s[pl][((long long)(c8 >> 5) * mx.srows + pix) * 8 + ((c8 >> 2) & 7)] = (char)sbyte;
+                    }
+                }
             }
             }
         }
@@ -583,7 +623,7 @@ int launch_typed(const avl_seg_op& op, hipStream_t s) {
             break;
         }
         case AVL_OP_DWCONV: {
-            if ((op.in_lo == nullptr) != (op.out_lo == nullptr)) {      // one side split only: the simple kernel
+            if ((op.in_lo == nullptr) != (op.out_lo == nullptr) && !op.out_mx) {      // one side split only: the simple kernel
                 hipLaunchKernelGGL(k_dwconv_split<T>, dim3(blocks_for((long long)op.out_h * op.out_w * (op.in_c / 8))), dim3(kThreads), 0, s,
                                    in, static_cast<const T*>(op.in_lo), w, op.bias, out, static_cast<T*>(op.out_lo), op.in_h, op.in_w,
                                    op.in_c, op.in_ld, op.out_h, op.out_w, op.out_ld, op.pad, op.dil, op.relu);
@@ -619,14 +659,23 @@ int launch_typed(const avl_seg_op& op, hipStream_t s) {
             g.upb = (op.dil == 1 || unit_px >= target) ? 1 : (target + unit_px - 1) / unit_px;
             const unsigned nblk = (unsigned)((g.units + g.upb - 1) / g.upb) * g.cgroups;
             if constexpr (sizeof(T) == 2) {
-                if (op.in_lo && op.out_lo) {
+                if (op.in_lo && (op.out_lo || op.out_mx)) {
+                    MxOut mx;
+                    memset(&mx, 0, sizeof(mx));
+                    if (op.out_mx) {
+                        char* b = static_cast<char*>(op.out_mx);
+                        const long long rows = op.out_rows, P = rows * (op.out_c / 2), S = (long long)(op.out_c / 256) * rows * 8;
+                        mx.q[0] = b; mx.s[0] = b + P;
+                        if (op.out_lo || (op.mx_flags & AVL_MX_OUT_LO)) { mx.q[1] = b + P + S; mx.s[1] = b + 2 * P + S; }
+                        mx.srows = rows; mx.ldq = op.out_c / 2;
+                    }
                     hipLaunchKernelGGL((k_dwconv<T, true>), dim3(nblk), dim3(kThreads), 0, s, in, w, op.bias, out,
-                                       static_cast<const T*>(op.in2), g, static_cast<const T*>(op.in_lo), static_cast<T*>(op.out_lo));
+                                       static_cast<const T*>(op.in2), g, static_cast<const T*>(op.in_lo), static_cast<T*>(op.out_lo), mx);
                     break;
                 }
             }
             hipLaunchKernelGGL((k_dwconv<T, false>), dim3(nblk), dim3(kThreads), 0, s, in, w, op.bias, out,
-                               static_cast<const T*>(op.in2), g, static_cast<const T*>(nullptr), static_cast<T*>(nullptr));
+                               static_cast<const T*>(op.in2), g, static_cast<const T*>(nullptr), static_cast<T*>(nullptr), MxOut());
             break;
         }
         case AVL_OP_BILINEAR:
@@ -687,6 +736,11 @@ int validate_conv_op(const avl_seg_op& op) {
     AVL_REQUIRE(op.in_ld >= op.in_c && op.out_ld >= op.out_c, "op %d: leading dims", op.kind);
     AVL_REQUIRE((op.in_ld * es) % 16 == 0 && (op.out_ld * es) % 16 == 0, "op %d: row strides must be 16-byte multiples", op.kind);
     AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.in) | reinterpret_cast<uintptr_t>(op.out)) % 16 == 0, "op %d: unaligned buffers", op.kind);
+    if (op.out_mx && op.kind == AVL_OP_DWCONV) {
+        AVL_REQUIRE(op.dtype == AVL_F16 && op.in_lo && op.out_c % 256 == 0 && op.out_ld == op.out_c && (op.in_c / 8) % 4 == 0,
+                    "dwconv: out_mx needs the split f16 form, channels %% 256 == 0 and a dense output");
+        AVL_REQUIRE(!(op.mx_flags & AVL_MX_OUT_LO) || !op.out_lo, "dwconv: AVL_MX_OUT_LO together with out_lo");
+    }
     if (op.in_lo || op.out_lo || op.in2_lo) {
         // split (hi + lo) planes: same shape and stride as the high plane; f16 only
         AVL_REQUIRE(op.dtype == AVL_F16 && !op.in2_lo, "op %d: split planes need AVL_F16 (and no in2_lo)", op.kind);

@@ -177,8 +177,12 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs<HT> p) {
                     pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[4], src[5], scale, 2);
                     pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[6], src[7], scale, 3);
                     const long long pix = (long long)oy * p.OW + ox;
-                    *reinterpret_cast<unsigned*>(p.oq[pl] + pix * (p.C / 2) + cbase / 2) = pk;
-                    if (kq == 0) p.os[pl][((long long)(cbase >> 8) * p.o_srows + pix) * 8 + ((cbase >> 5) & 7)] = (char)sbyte;
+                    // the window's 16 bytes leave through its kq = 0 lane as ONE store
+                    const unsigned p1 = __shfl(pk, lane + 16), p2 = __shfl(pk, lane + 32), p3 = __shfl(pk, lane + 48);
+                    if (kq == 0) {
+                        *reinterpret_cast<uint4*>(p.oq[pl] + pix * (p.C / 2) + cbase / 2) = make_uint4(pk, p1, p2, p3);
+                        p.os[pl][((long long)(cbase >> 8) * p.o_srows + pix) * 8 + ((cbase >> 5) & 7)] = (char)sbyte;
+                    }
                 }
             }
         }

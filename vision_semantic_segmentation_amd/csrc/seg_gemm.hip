@@ -878,10 +878,11 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
                     if (q.Cq[pl] == nullptr) continue;
                     unsigned pk[2];
                     const unsigned sb = quantize_fp4_block(pl == 0 ? hi : lo, pk);
-                    if (live) {
-                        *reinterpret_cast<uint2*>(q.Cq[pl] + (long long)m * q.ldcq + nbase / 2) = make_uint2(pk[0], pk[1]);
-                        if ((kq & 1) == 0)
-                            q.Cs[pl][((long long)(nbase >> 8) * q.c_srows + m) * 8 + ((nbase >> 5) & 7)] = (char)sb;
+                    // the block's 16 bytes (this lane's 8 + its partner's) leave through the even-kq lane as ONE store
+                    const unsigned p2 = __shfl_xor(pk[0], 16), p3 = __shfl_xor(pk[1], 16);
+                    if (live && (kq & 1) == 0) {
+                        *reinterpret_cast<uint4*>(q.Cq[pl] + (long long)m * q.ldcq + nbase / 2) = make_uint4(pk[0], pk[1], p2, p3);
+                        q.Cs[pl][((long long)(nbase >> 8) * q.c_srows + m) * 8 + ((nbase >> 5) & 7)] = (char)sb;
                     }
                 }
             }

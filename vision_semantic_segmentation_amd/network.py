@@ -522,7 +522,8 @@ class SegNet(object):
             f["out_lo"] = self._lo(dst, dst_col)
             if kind != OP_GCONV:
                 f["in_lo"] = self._lo(src)
-            elif isinstance(dst, Act) and dst.mx is not None and extra.get("w_layout") == 1:
+            if (isinstance(dst, Act) and dst.mx is not None and dst_col == 0
+                    and ((kind == OP_GCONV and extra.get("w_layout") == 1) or (kind == OP_DWCONV and f.get("in_lo")))):
                 f["out_mx"] = dst.mx.data_ptr()
                 dst.mx_valid = True
                 if dst.lo_fp4:
@@ -726,7 +727,9 @@ class SegNet(object):
                 self._release(x)
             else:
                 wd_, bd_ = self._dev(w.reshape(cin, 9).t().reshape(-1), torch.float32), self._dev(b, torch.float32)
-                t = self._act(ohw[0] * ohw[1], cin, split=self.mixed)
+                # mixed: the depthwise output feeds an MX GEMM where shapes allow (f16 plane + FP4 copies, lo part as FP4 only)
+                t_fp4 = self.mixed_mx and self.mixed_trunk_fp4 and cin % 256 == 0 and w2.shape[0] % 256 == 0 and x.lo is not None
+                t = self._act(ohw[0] * ohw[1], cin, split=self.mixed, mx=t_fp4, lo_fp4=t_fp4)
                 self._spatial(p + ".depthwise_cnn", OP_DWCONV, x, hw, cin, t, ohw, cin, wd_, bd_, ksize=3, stride=1, pad=0, dil=1, groups=cin, relu=1,
                               in2=self.zero_page.data_ptr())
                 self._release(x)
