@@ -520,3 +520,71 @@ def test_split_depthwise_writes_the_mx_bundle(case, cuda_device):
 def _from_rows_inv(x, m, c):
     """[1,C,H,W] -> [H*W][C]"""
     return x[0].permute(1, 2, 0).reshape(m, c)
+
+
+@pytest.mark.parametrize("case", [(23, 45, 256, 1, 1), (30, 41, 512, 1, 2), (19, 67, 1024, 1, 4), (26, 40, 256, 2, 1)])
+@pytest.mark.parametrize("in_lo", [False, True])
+def test_mx_grouped_conv(case, in_lo, cuda_device):
+    """k_gconv_mx: f16 hi product + FP4 corrections Q4(W lo) x Q4(x hi) [+ Q4(W hi) x Q4(x lo)], the input given as an f16 plane plus
+    its MX bundle.  Reference: float64 evaluation of exactly that sum (the FP4 operands dequantised on the host)."""
+    import torch
+    import torch.nn.functional as F
+    from test_gpu_ops import _from_rows, _nhwc_rows, _spatial_op
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import (AVL_MX_IN_LO, AVL_MX_OUT_LO, OP_GCONV, fp4_quant_blocks, gconv_dense_windows,
+                                                          mx_bundle_bytes, mx_dequant_fp4, mx_quant_fp4, pack_gconv_mx)
+    H, W, width, s, d = case
+    G = 32
+    cg = width // G
+    g = torch.Generator().manual_seed(H * 77 + W + width)
+    x64 = torch.randn((1, width, H, W), generator=g, dtype=torch.float64) * torch.exp2(torch.randint(-2, 3, (1, width, 1, 1), generator=g).double())
+    x_hi, x_lo = _split(x64)
+    w64 = torch.randn((width, cg, 3, 3), generator=g, dtype=torch.float64) * (2.0 / (cg * 9)) ** 0.5
+    b = torch.randn(width, generator=g) * 0.1
+    OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+    M_in = H * W
+    rows_in = (M_in + 255) // 256 * 256
+    # what the kernel multiplies: FP4 images of the activations per (pixel, 32-channel window) and of the weights per (row, tap, window)
+    def deq_act(t):                                     # [1,C,H,W] -> same, through the MX bundle layout
+        r = _pad_rows(t[0].permute(1, 2, 0).reshape(M_in, width).double(), rows_in)
+        dq = mx_dequant_fp4(*mx_quant_fp4(r))[:M_in]
+        return dq.reshape(H, W, width).permute(2, 0, 1).unsqueeze(0)
+    w_hi, w_lo = _split(w64)
+
+    def deq_w(part):                                    # weights quantised per (output channel, tap, window of 32 input channels)
+        dense = gconv_dense_windows(part.double(), G)                                  # [win][32 co][9][32 ci]
+        codes, sb = fp4_quant_blocks(dense)
+        from vision_semantic_segmentation_amd.network import _FP4_GRID
+        c = codes.to(torch.int64)
+        code = torch.stack([c & 15, c >> 4], dim=-1).reshape(*dense.shape)
+        val = _FP4_GRID[code & 7] * torch.where((code & 8) != 0, -1.0, 1.0) * torch.exp2(sb.double() - 127).unsqueeze(-1)
+        out = torch.zeros_like(part, dtype=torch.float64).reshape(width, cg, 9)
+        co = torch.arange(width)
+        win, col = co // 32, co % 32
+        gbase = (col // cg) * cg
+        for ci in range(cg):
+            out[co, ci, :] = val[win, col, :, gbase + ci]
+        return out.reshape(width, cg, 3, 3)
+    conv = lambda xx, ww: F.conv2d(xx, ww, None, stride=s, padding=d, dilation=d, groups=G)      # noqa: E731
+    ref = conv(x_hi.double(), w_hi.double()) + conv(deq_act(x_hi), deq_w(w_lo)) + b.double().view(1, -1, 1, 1)
+    if in_lo:
+        ref = ref + conv(deq_act(x_lo), deq_w(w_hi))
+    ref = F.relu(ref)
+    src = _nhwc_rows(x_hi).to(cuda_device)
+    in_mx = _bundle(_pad_rows(x_hi[0].permute(1, 2, 0).reshape(M_in, width), M_in), _pad_rows(x_lo[0].permute(1, 2, 0).reshape(M_in, width), M_in),
+                    rows_in).to(cuda_device)
+    rows = (OH * OW + 255) // 256 * 256
+    dst = torch.full((rows, width), 7.0, dtype=torch.float16, device=cuda_device)
+    out_mx = torch.zeros(2 * mx_bundle_bytes(rows, width), dtype=torch.uint8, device=cuda_device)
+    frag, bundle = pack_gconv_mx(w64, G)
+    wd, wb, bd = frag.reshape(-1).to(cuda_device), bundle.to(cuda_device), b.to(cuda_device)
+    _run_plan([_spatial_op(OP_GCONV, _lib.AVL_F16, src, (H, W), width, dst, (OH, OW), width, weight=wd.data_ptr(), bias=bd.data_ptr(),
+                           ksize=3, stride=s, pad=d, dil=d, groups=G, relu=1, w_layout=1, w_split=2, w_mx=wb.data_ptr(), in_mx=in_mx.data_ptr(),
+                           out_mx=out_mx.data_ptr(), mx_flags=(AVL_MX_IN_LO if in_lo else 0) | AVL_MX_OUT_LO)])
+    M = OH * OW
+    v_lo = _unbundle(out_mx.cpu(), rows, width, 1)[2][:M]
+    got = dst[:M].cpu().double() + v_lo
+    want = ref[0].permute(1, 2, 0).reshape(M, width)
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err <= 2 ** -11 * 0.3, "mx grouped conv %s in_lo=%s: %.3e" % (case, in_lo, err)
+    assert torch.all(dst[M:] == 7.0)

@@ -204,6 +204,47 @@ def pack_gconv_windows(w, groups):
     return out.reshape(-1)
 
 
+def gconv_dense_windows(w, groups):
+    """Grouped 3x3 weights [C][C/groups][3][3] -> dense block-diagonal windows float64 [window][co_local 32][tap 9][ci_local 32]."""
+    C_ = w.shape[0]
+    cg = C_ // groups
+    nwin = C_ // 32
+    dense = torch.zeros((nwin, 32, 9, 32), dtype=torch.float64)
+    wt = w.reshape(C_, cg, 9).to(torch.float64)
+    co = torch.arange(C_)
+    win, col = co // 32, co % 32
+    gbase = (col // cg) * cg
+    for ci in range(cg):
+        dense[win, col, :, gbase + ci] = wt[co, ci, :]
+    return dense
+
+
+def pack_gconv_mx(w, groups):
+    """The MX grouped conv's weights (k_gconv_mx): float64 [C][C/groups][3][3] (BN folded) ->
+      hi fragments  float16 [window][nj 2][tap 9][i 16][ci 32]                  (as pack_gconv_windows, of the f16 hi part)
+      FP4 bundle    uint8: [window][nj 2][pair 2][g 3][lane 64][16 B] then [window][lane 64][12 B] scale bytes
+    pair 0 = Q4(W lo) (multiplies Q4(x hi)), pair 1 = Q4(W hi) (multiplies Q4(x lo)); scaled MFMA g covers taps 4g .. 4g+3 (K block
+    kb = tap 4g + kb, its 32 values the window's input channels; taps >= 9 are zero); lane = kb * 16 + i, MFMA row i of n-tile nj
+    being output channel (i>>2)*8 + nj*4 + (i&3) of the window; scale byte index nj * 6 + pair * 3 + g."""
+    whi, wlo = split_f16(w)
+    nwin = w.shape[0] // 32
+    frag_hi = pack_gconv_windows(whi.to(torch.float64), groups).to(torch.float16)
+    i = torch.arange(16)
+    w4 = torch.zeros((nwin, 2, 2, 3, 64, 16), dtype=torch.uint8)
+    w4s = torch.zeros((nwin, 64, 12), dtype=torch.uint8)
+    for pair, part in ((0, wlo), (1, whi)):
+        dense = gconv_dense_windows(part.to(torch.float64), groups)                        # [win][32][9][32]
+        for nj in range(2):
+            rows = (i >> 2) * 8 + nj * 4 + (i & 3)
+            d = torch.zeros((nwin, 16, 12, 32), dtype=torch.float64)
+            d[:, :, :9] = dense[:, rows]
+            codes, sbyte = fp4_quant_blocks(d.reshape(nwin, 16, 3, 4, 32))                 # [win][i][g][kb][16], [win][i][g][kb]
+            w4[:, nj, pair] = codes.permute(0, 2, 3, 1, 4).reshape(nwin, 3, 64, 16)         # lane = kb * 16 + i
+            sb = sbyte.permute(0, 3, 1, 2).reshape(nwin, 64, 3).to(torch.uint8)             # [win][lane][g]
+            w4s[:, :, nj * 6 + pair * 3:nj * 6 + pair * 3 + 3] = sb
+    return frag_hi, torch.cat([w4.reshape(-1), w4s.reshape(-1)])
+
+
 def pack_dw_pairs(w, b, act_dtype):
     """Depthwise parameters for the fused depthwise+pointwise kernel (AVL_OP_DWPW): w float64 [C][1][3][3] and b [C]
     (BN folded) -> int32 [C/64][chunk 8][6][8]: five tap pairs per channel (tap 2p in the low half, tap 2p+1 in the
@@ -260,28 +301,33 @@ def pack_split_rows(w, nsub):
 _FP4_GRID = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0], dtype=torch.float64)
 
 
-def mx_quant_fp4(w):
-    """float64 [rows][K] (K % 256 == 0) -> (uint8 [rows][K/2], uint8 [K/256][rows][8]): OCP MX-FP4 along K as libavl_hip's
-    MX GEMM reads it (include/avl_hip.h, w_split = 2): blocks of 32, scale byte = biased exponent of the block maximum - 2
-    (the maximum lands in [4, 8) and saturates to 6), e2m1 elements rounded to nearest even, element 2i in the LOW nibble of
-    byte i -- the convention of the GPU's v_cvt_scalef32_pk_fp4_f32 (tools/micro/fp4_cvt_probe.hip)."""
-    rows, k = w.shape
-    assert k % 256 == 0
-    b = w.reshape(rows, k // 32, 32).to(torch.float64)
-    amax = b.abs().amax(dim=2)
+def fp4_quant_blocks(b):
+    """float64 [..., 32] -> (uint8 [..., 16], int64 [...]): one OCP MX-FP4 block per trailing 32 values: scale byte = biased
+    exponent of the block maximum - 2 (the maximum lands in [4, 8) and saturates to 6), e2m1 elements rounded to nearest even,
+    element 2i in the LOW nibble of byte i -- the convention of the GPU's v_cvt_scalef32_pk_fp4_f32 (tools/micro/fp4_cvt_probe.hip)."""
+    b = b.to(torch.float64)
+    amax = b.abs().amax(dim=-1)
     e = torch.floor(torch.log2(amax.clamp_min(2.0 ** -120))).to(torch.int64) + 127           # biased exponent of amax
     sbyte = torch.where(e >= 3, e - 2, torch.ones_like(e)).clamp(1, 254)
-    scale = torch.exp2((sbyte - 127).to(torch.float64)).unsqueeze(2)
+    scale = torch.exp2((sbyte - 127).to(torch.float64)).unsqueeze(-1)
     mag = (b.abs() / scale).clamp_max(6.0)
     mid = (_FP4_GRID[1:] + _FP4_GRID[:-1]) / 2
     code = torch.bucketize(mag, mid, right=False)                  # ties go to the lower code ...
-    tie = mag == mid[(code - 0).clamp(0, 6)]                        # (bucketize(right=False): mag == mid[i] -> i)
+    tie = mag == mid[code.clamp(0, 6)]                              # (bucketize(right=False): mag == mid[i] -> i)
     code = torch.where(tie & (code % 2 == 1), code + 1, code)       # ... unless that one is odd: round half to even mantissa
     code = code.clamp(0, 7) | ((b < 0).to(torch.int64) << 3)
-    code = code.reshape(rows, k // 2, 2)
-    packed = (code[:, :, 0] | (code[:, :, 1] << 4)).to(torch.uint8)
+    code = code.reshape(*code.shape[:-1], 16, 2)
+    return (code[..., 0] | (code[..., 1] << 4)).to(torch.uint8), sbyte
+
+
+def mx_quant_fp4(w):
+    """float64 [rows][K] (K % 256 == 0) -> (uint8 [rows][K/2], uint8 [K/256][rows][8]): OCP MX-FP4 along K as libavl_hip's
+    MX GEMM reads it (include/avl_hip.h, w_split = 2): blocks of 32 (fp4_quant_blocks), scales laid out per 256-wide K block."""
+    rows, k = w.shape
+    assert k % 256 == 0
+    packed, sbyte = fp4_quant_blocks(w.reshape(rows, k // 32, 32))
     scales = sbyte.reshape(rows, k // 256, 8).permute(1, 0, 2).contiguous().to(torch.uint8)
-    return packed, scales
+    return packed.reshape(rows, k // 2), scales
 
 
 def mx_dequant_fp4(packed, scales):
@@ -345,6 +391,7 @@ class SegNet(object):
         self.mixed_mx = self.mixed and mixed_opts.get("mx", True)
         self.mixed_trunk_fp4 = mixed_opts.get("trunk_fp4", True)
         self.mixed_fuse_ds = mixed_opts.get("fuse_ds", True)     # stride-1 downsample folded into conv3 (second input along K)
+        self.mixed_gconv_mx = mixed_opts.get("gconv_mx", True)   # grouped conv with FP4 corrections for its weights AND for conv1's output
         self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "mixed": torch.float16}[precision]
         self.avl_dtype = {"bf16": _lib.AVL_BF16, "f16": _lib.AVL_F16, "f32": _lib.AVL_F32, "mixed": _lib.AVL_F16}[precision]
         self.half = precision != "f32"              # 16-bit activations: MFMA stem / grouped-conv kernels
@@ -528,6 +575,7 @@ class SegNet(object):
                 dst.mx_valid = True
                 if dst.lo_fp4:
                     f["mx_flags"] = AVL_MX_OUT_LO
+        f["mx_flags"] = f.get("mx_flags", 0) | extra.pop("mx_flags", 0)
         f.update(extra)
         self._op(name, kind, **f)
 
@@ -575,12 +623,25 @@ class SegNet(object):
                 ohw = ((hw[0] + 2 * d - 2 * d - 1) // s + 1, (hw[1] + 2 * d - 2 * d - 1) // s + 1)
                 # conv1 1x1 + bn1 + relu
                 w, b = fold_bn(st, p + ".conv1.weight", p + ".bn1")
-                t1 = self._act(hw[0] * hw[1], width)
+                # where conv1 runs as an MX GEMM its output keeps FP4 copies of both parts (the lo part only so): the grouped conv
+                # then corrects for the rounding of conv1's output too -- the largest single error term otherwise
+                conv1_mx = (self.mixed_mx and self.mixed_gconv_mx and x.mx is not None and x.mx_valid and x.hi.shape[1] == cin
+                            and cin % 256 == 0 and width % 256 == 0 and 32 % (width // GROUPS) == 0)
+                t1 = self._act(hw[0] * hw[1], width, mx=conv1_mx, lo_fp4=conv1_mx)
                 self._gemm(p + ".conv1", x, hw, cin, w, b, t1, read_lo=self.mixed_conv1_split)
                 # conv2 3x3 grouped + bn2 + relu
                 w, b = fold_bn(st, p + ".conv2.weight", p + ".bn2")
                 cg = width // GROUPS
-                if self.half and width % 64 == 0 and 32 % cg == 0:
+                gconv_mx = self.mixed and t1.mx is not None and t1.mx_valid and t1.lo_fp4
+                wsplit = int(self.mixed)
+                extra_g = {}
+                if gconv_mx:
+                    frag_hi, bundle = pack_gconv_mx(w, GROUPS)
+                    wg_d, layout, wsplit = self._dev(frag_hi.reshape(-1), torch.float16), 1, 2
+                    wb = bundle.to(self.device)
+                    self._keep.append(wb)
+                    extra_g = dict(w_mx=wb.data_ptr(), in_mx=t1.mx.data_ptr(), mx_flags=AVL_MX_IN_LO)
+                elif self.half and width % 64 == 0 and 32 % cg == 0:
                     if self.mixed:       # f16 pairs: 18 "taps" = 9 hi + 9 lo per window and n-tile
                         nwin = width // 32
                         whi, wlo = split_f16(w)
@@ -597,7 +658,7 @@ class SegNet(object):
                 t2_fp4 = self.mixed_conv2_split and self.mixed_trunk_fp4 and width % 256 == 0 and cout % 256 == 0 and layout == 1
                 t2 = self._act(ohw[0] * ohw[1], width, split=self.mixed_conv2_split, mx=True, lo_fp4=t2_fp4)
                 self._spatial(p + ".conv2", OP_GCONV, t1, hw, width, t2, ohw, width, wg_d, bg_d, ksize=3, stride=s, pad=d, dil=d,
-                              groups=GROUPS, relu=1, w_layout=layout, w_split=int(self.mixed))
+                              groups=GROUPS, relu=1, w_layout=layout, w_split=wsplit, **extra_g)
                 self._release(t1)
                 # identity / downsample.  Stride-1 downsamples (layer3.0, layer4.0) whose input and the 3x3 output both carry MX
                 # bundles are folded into conv3 as a second input along K: the identity tensor never exists
