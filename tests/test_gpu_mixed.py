@@ -289,6 +289,25 @@ def test_mixed_logits_within_1e3_of_oracle(state, hw, cuda_device):
     assert agree >= 0.998
 
 
+def test_mixed_logits_with_the_mx_grouped_conv(state, cuda_device):
+    """MODEL.MIXED_GCONV_MX = True (FP4 corrections inside the grouped 3x3 as well): same 1e-3 bound, through the cfg switch."""
+    import numpy as np
+    from oracle import network_oracle as no
+    from test_gpu_seg import _cfg
+    from vision_semantic_segmentation_amd import SemanticSegmentation
+    cfg = _cfg("mixed")
+    cfg.MODEL.MIXED_GCONV_MX = True
+    seg = SemanticSegmentation(cfg, device=cuda_device, state_dict=state)
+    img = np.random.default_rng(0).integers(0, 256, size=(320, 416, 3), dtype=np.uint8)
+    got = seg.logits(img).cpu()
+    from vision_semantic_segmentation_amd.network import OP_GCONV
+    assert any(op.w_split == 2 and op.kind == OP_GCONV for op in seg.net_for(320, 416).ops)
+    ref = no.forward_logits(state, img)[0]
+    rel = float((got - ref).abs().max() / ref.abs().max())
+    print("mixed + MX grouped conv 320x416: max rel err %.3e" % rel)
+    assert rel <= 1e-3
+
+
 def _bundle(hi64, lo64, rows_pad):
     """MX bundle [Q4(hi) | scales | Q4(lo) | scales] of a split tensor, rows padded with zeros"""
     import torch

@@ -37,65 +37,72 @@ struct GconvArgs {
     int th;              // output tile height (8, or 4 for stride 2)
     int tiles_x, tiles_y, cchunks;
     int comb;            // 1: stride 1, dilation d > 1 -> tiles live on the d x d residue-class grids (see below)
+    int nsp, nslots;     // pixel tiles (all residue classes), and how many of them are in flight (workgroups per channel chunk)
+    int tile_bytes;      // one LDS tile buffer
 };
 
 // WS = 1 ("mixed" precision): the weights come as f16 pairs hi + lo ([window][nj 2][tap 18 = 9 hi, 9 lo][16][32]); both
 // parts multiply the same input fragment into the same accumulator (fp32), i.e. the weights keep ~22 significant bits.
-template <typename HT, int WS = 0>
-__global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs<HT> p) {
+template <typename HT, int WS, int NJ>      // NJ = tile height / 2: sub-tiles per wave and tile
+__global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
     typedef typename Half16<HT>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid = blockIdx.x;
-    const int cchunk = bid % p.cchunks;
-    bid /= p.cchunks;
-    const int tx = bid % p.tiles_x;
-    bid /= p.tiles_x;
-    const int ty = bid % p.tiles_y, cmb = bid / p.tiles_y;
+    {
+        // XCD-aware, bijective remap (workgroups b, b+8, ... share an XCD and its L2): each XCD takes a contiguous run of
+        // (slot, channel chunk) pairs, so neighbouring tiles share their halo in one L2
+        const int nwg = gridDim.x, xcd = bid & 7, local = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    // PERSISTENT: the launch is one workgroup per CU; workgroup (slot, channel chunk) keeps its chunk's weight fragments in
+    // registers and walks the pixel tiles slot, slot + nslots, ... with TWO LDS tile buffers: the LDS-DMA of the next tile is
+    // in flight while this tile's sub-tiles go through the matrix cores (one barrier per tile).
+    const int cchunk = bid % p.cchunks, slot = bid / p.cchunks;
     // Dilated layers (stride 1, pad = d): the outputs with (y mod d, x mod d) = (ry, rx) read only inputs of the same
     // residue class, so a tile is cut from that class's grid and is an ordinary d = 1 tile there: the halo is
-    // (8+2) x (32+2) pixels instead of (8+2d) x (32+2d) (2.5x the tile at d = 4), LDS drops from 80 KB to 43.5 KB.
+    // (8+2) x (32+2) pixels instead of (8+2d) x (32+2d) (2.5x the tile at d = 4).
     const int s = p.stride;
     const int d = p.comb ? 1 : p.dil;            // tap distance inside the LDS tile
     const int step = p.comb ? p.dil : 1;         // image pixels per tile-grid step
-    const int ry = p.comb ? cmb / p.dil : 0, rx = p.comb ? cmb % p.dil : 0;
-    const int oy0 = ty * p.th, ox0 = tx * TW;    // tile origin on its grid
     const int in_th = (p.th - 1) * s + 2 * d + 1, in_tw = (TW - 1) * s + 2 * d + 1;
-    const int iy0 = ry + (oy0 * s - d) * step, ix0 = rx + (ox0 * s - d) * step;
     const int c0 = cchunk * CC;
-
-    // ---- stage the input tile (+halo) by LDS-DMA: one wave-instruction = 8 pixels x 128 B, all of a wave's
-    // transfers in flight at once.  The DMA writes LDS lane-linearly, so the chunk swizzle goes on the SOURCE
-    // address.  Pixels outside the image are fetched from a clamped address and zeroed afterwards.
     const int npix = in_th * in_tw;
     const int ngroups = (npix + 7) >> 3;
-    unsigned oob = 0;
-    {
+    const unsigned lds0 = lds_addr(lds);
+
+    // ---- stage one input tile (+halo) by LDS-DMA: one wave-instruction = 8 pixels x 128 B, all of a wave's transfers in
+    // flight at once.  The DMA writes LDS lane-linearly, so the chunk swizzle goes on the SOURCE address.  Pixels outside
+    // the image are fetched from a clamped address and zeroed once the data has landed (bit mask returned).  The DMA is
+    // issued from inline asm: the compiler does not see it, so it neither drains it in front of the ds_reads of the OTHER
+    // buffer nor needs to -- completion is the hand-placed s_waitcnt vmcnt(0) at the top of the tile loop.
+    auto stage = [&](int sp, int buf) -> unsigned {
+        const int tx = sp % p.tiles_x, r1 = sp / p.tiles_x;
+        const int ty = r1 % p.tiles_y, cmb = r1 / p.tiles_y;
+        const int ry = p.comb ? cmb / p.dil : 0, rx = p.comb ? cmb % p.dil : 0;
+        const int iy0 = ry + (ty * p.th * s - d) * step, ix0 = rx + (tx * TW * s - d) * step;
         const int prow = lane >> 3, cphys = lane & 7;
+        unsigned oob = 0;
         int it = 0;
-        for (int gi = wave; gi < ngroups; gi += 4, ++it) {
+        for (int gi = wave; gi < ngroups; gi += 8, ++it) {
             const int pix = gi * 8 + prow;
             const int ly = pix / in_tw, lx = pix - ly * in_tw;
             const int iy = iy0 + ly * step, ix = ix0 + lx * step;
             const bool inside = pix < npix && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
             const HT* src = p.in + ((long long)cy * p.W + cx) * p.in_ld + c0 + ((cphys ^ (pix & 7)) << 3);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + gi * 1024), 16, 0, 0);
+            glds16_asm(src, lds0 + buf * p.tile_bytes + gi * 1024);
             oob |= (inside ? 0u : 1u) << it;
         }
-        if (oob) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            it = 0;
-            for (int gi = wave; gi < ngroups; gi += 4, ++it)
-                if ((oob >> it) & 1u) *reinterpret_cast<uint4*>(lds + gi * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
-        }
-    }
+        return oob;
+    };
+    int sp = slot, buf = 0;
+    unsigned oob = sp < p.nsp ? stage(sp, 0) : 0u;
 
-    // ---- this wave's window and its weight fragments (registers for the whole tile)
+    // ---- this wave's window and its weight fragments (registers for ALL of the workgroup's tiles)
     const int win = wave & 1;                  // window inside the 64-channel chunk
-    const int half = wave >> 1;                // which half of the tile's sub-tiles
+    const int part = wave >> 1;                // which quarter of each tile's sub-tiles
     const int fr = lane & 15, kq = lane >> 4;
     constexpr int NT = WS ? 18 : 9;
     v8 wf[2][NT];
@@ -109,47 +116,91 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs<HT> p) {
     }
     // lane's 8 output channels: window base + q*8 + nj*4 + r
     const int cbase = c0 + win * 32 + kq * 8;
-    float bias[8];
-    {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cbase);
-        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cbase + 4);
-        bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
-        bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
-    }
+    const int chunk_in = win * 4 + kq;         // this lane's 16-byte chunk of the pixel row (8 input channels)
+
+    // the first tile has landed; zero what lies outside the image
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto zero_oob = [&](unsigned mask, int b) {
+        if (mask) {
+            int it = 0;
+            for (int gi = wave; gi < ngroups; gi += 8, ++it)
+                if ((mask >> it) & 1u) *reinterpret_cast<uint4*>(lds + b * p.tile_bytes + gi * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    zero_oob(oob, 0);
     __syncthreads();
 
-    const int nsub = p.th * (TW / 16);         // sub-tiles of 16 pixels in the tile
-    const int chunk_in = win * 4 + kq;         // this lane's 16-byte chunk of the pixel row (8 input channels)
-    for (int st = half; st < nsub; st += 2) {
-        const int sy = st >> 1, sx = (st & 1) * 16 + fr;        // output pixel (tile-local) of this lane
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        // all nine tap fragments are requested before the first MFMA: the LDS latency is paid once per sub-tile,
-        // not once per tap (the read -> 2 MFMA -> read chain left the matrix pipe idle ~2/3 of the time)
-        v8 a[9];
+    // Per tile: [DMA of the next tile -> other buffer] [MFMA phase: this wave's sub-tiles, results stay in registers]
+    // [s_waitcnt vmcnt(0): the next tile has landed -- the only older stores are those of the PREVIOUS tile, long retired, so
+    // the wait never sits on fresh stores] [epilogue phase: bias, ReLU, hi/lo split, FP4 copies, stores] [barrier].
+    for (; sp < p.nsp; sp += p.nslots, buf ^= 1) {
+        oob = sp + p.nslots < p.nsp ? stage(sp + p.nslots, buf ^ 1) : 0u;
+        const char* tile = lds + buf * p.tile_bytes;
+        f32x4 acc[NJ][2];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int pix = (sy * s + (t / 3) * d) * in_tw + sx * s + (t % 3) * d;
-            a[t] = *reinterpret_cast<const v8*>(lds + pix * 128 + ((chunk_in ^ (pix & 7)) << 4));
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < NJ; ++j) {
+            const int st = part + 4 * j;
+            int frv = fr;
+            asm volatile("" : "+v"(frv));       // the LDS addresses are tile-invariant: recompute them (a few VALU ops) rather than keep 9 x NJ of them in registers
+            const int sy = st >> 1, sx = (st & 1) * 16 + frv;        // output pixel (tile-local) of this lane
+            // all nine tap fragments are requested before the first MFMA: the LDS latency is paid once per sub-tile
+            v8 a[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            acc0 = Half16<HT>::mfma(wf[0][t], a[t], acc0);
-            acc1 = Half16<HT>::mfma(wf[1][t], a[t], acc1);
-            if constexpr (WS != 0) {
-                acc0 = Half16<HT>::mfma(wf[0][9 + t], a[t], acc0);
-                acc1 = Half16<HT>::mfma(wf[1][9 + t], a[t], acc1);
+            for (int t = 0; t < 9; ++t) {
+                const int pix = (sy * s + (t / 3) * d) * in_tw + sx * s + (t % 3) * d;
+                a[t] = *reinterpret_cast<const v8*>(tile + pix * 128 + ((chunk_in ^ (pix & 7)) << 4));
             }
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (WS != 0) {
+                // four independent accumulator chains (hi and lo weights apart): no MFMA waits for its predecessor
+                f32x4 acl0 = {0.f, 0.f, 0.f, 0.f}, acl1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    acc0 = Half16<HT>::mfma(wf[0][t], a[t], acc0);
+                    acc1 = Half16<HT>::mfma(wf[1][t], a[t], acc1);
+                    acl0 = Half16<HT>::mfma(wf[0][9 + t], a[t], acl0);
+                    acl1 = Half16<HT>::mfma(wf[1][9 + t], a[t], acl1);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc0[r] += acl0[r]; acc1[r] += acl1[r]; }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    acc0 = Half16<HT>::mfma(wf[0][t], a[t], acc0);
+                    acc1 = Half16<HT>::mfma(wf[1][t], a[t], acc1);
+                }
+            }
+            acc[j][0] = acc0; acc[j][1] = acc1;
+            __builtin_amdgcn_sched_barrier(0);      // keep the next sub-tile's nine fragments out of this one's registers
         }
-        const int oy = ry + (oy0 + sy) * step, ox = rx + (ox0 + sx) * step;
-        if (oy < p.OH && ox < p.OW) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        zero_oob(oob, buf ^ 1);
+
+        const int tx = sp % p.tiles_x, r1 = sp / p.tiles_x;
+        const int ty = r1 % p.tiles_y, cmb = r1 / p.tiles_y;
+        const int ry = p.comb ? cmb / p.dil : 0, rx = p.comb ? cmb % p.dil : 0;
+        const int oy0 = ty * p.th, ox0 = tx * TW;    // tile origin on its grid
+        float bias[8];
+        {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cbase);
+            const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cbase + 4);
+            bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
+            bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int st = part + 4 * j;
+            const int sy = st >> 1, sx = (st & 1) * 16 + fr;
+            const int oy = ry + (oy0 + sy) * step, ox = rx + (ox0 + sx) * step;
+            const bool live = oy < p.OH && ox < p.OW;
+            const long long pix = live ? (long long)oy * p.OW + ox : 0;
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[r] = fmaxf(acc0[r] + bias[r], 0.f);
-                v[4 + r] = fmaxf(acc1[r] + bias[4 + r], 0.f);
+                v[r] = fmaxf(acc[j][0][r] + bias[r], 0.f);
+                v[4 + r] = fmaxf(acc[j][1][r] + bias[4 + r], 0.f);
             }
-            Vec8<HT>::store(p.out + ((long long)oy * p.OW + ox) * p.out_ld + cbase, v);
+            if (live) Vec8<HT>::store(p.out + pix * p.out_ld + cbase, v);
             if constexpr (WS != 0) {
                 float lo[8];
 #pragma unroll
@@ -159,8 +210,9 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs<HT> p) {
                     if (p.out_lo) lo[r] = (float)(HT)lo[r];        // a stored lo plane is f16: its FP4 copy is taken from what it holds
                     v[r] = h;
                 }
-                if (p.out_lo) Vec8<HT>::store(p.out_lo + ((long long)oy * p.OW + ox) * p.out_ld + cbase, lo);
-                // FP4 copies: the window's 32 channels (the four kq lanes of this pixel) are one MX block
+                if (p.out_lo && live) Vec8<HT>::store(p.out_lo + pix * p.out_ld + cbase, lo);
+                // FP4 copies: the window's 32 channels (the four kq lanes of this pixel) are one MX block.  The four lanes sit
+                // 16 apart: v_permlane16_swap / v_permlane32_swap exchange them at VALU speed (no LDS round trip).
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
                     if (p.oq[pl] == nullptr) continue;
@@ -168,8 +220,13 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs<HT> p) {
                     float amax = 0.f;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) amax = fmaxf(amax, fabsf(src[r]));
-                    amax = fmaxf(amax, __shfl_xor(amax, 16));
-                    amax = fmaxf(amax, __shfl_xor(amax, 32));
+                    {
+                        const unsigned ab = __float_as_uint(amax);
+                        const auto r16 = __builtin_amdgcn_permlane16_swap(ab, ab, false, false);       // rows (0,0,2,2) / (1,1,3,3)
+                        const unsigned m16 = max(r16[0], r16[1]);                                        // non-negative floats order as integers
+                        const auto r32 = __builtin_amdgcn_permlane32_swap(m16, m16, false, false);
+                        amax = __uint_as_float(max(r32[0], r32[1]));
+                    }
                     const unsigned e = __float_as_uint(amax) >> 23;
                     const unsigned sbyte = e >= 3u ? e - 2u : 1u;
                     const float scale = __uint_as_float(sbyte << 23);
@@ -178,16 +235,19 @@ __global__ void __launch_bounds__(256) k_gconv_mfma(GconvArgs<HT> p) {
                     pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[2], src[3], scale, 1);
                     pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[4], src[5], scale, 2);
                     pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[6], src[7], scale, 3);
-                    const long long pix = (long long)oy * p.OW + ox;
-                    // the window's 16 bytes leave through its kq = 0 lane as ONE store
-                    const unsigned p1 = __shfl(pk, lane + 16), p2 = __shfl(pk, lane + 32), p3 = __shfl(pk, lane + 48);
-                    if (kq == 0) {
-                        *reinterpret_cast<uint4*>(p.oq[pl] + pix * (p.C / 2) + cbase / 2) = make_uint4(pk, p1, p2, p3);
+                    // the window's 16 bytes leave through its kq = 0 lane as ONE store: row 0 collects rows 1, 2, 3
+                    const auto g16 = __builtin_amdgcn_permlane16_swap(pk, pk, false, false);           // [1]: rows (1,1,3,3)
+                    const auto g32 = __builtin_amdgcn_permlane32_swap(pk, pk, false, false);           // [1]: rows (2,3,2,3)
+                    const auto g48 = __builtin_amdgcn_permlane32_swap(g16[1], g16[1], false, false);   // [1]: rows (3,3,3,3)
+                    if (kq == 0 && live) {
+                        *reinterpret_cast<uint4*>(p.oq[pl] + pix * (p.C / 2) + cbase / 2) = make_uint4(pk, g16[1], g32[1], g48[1]);
                         p.os[pl][((long long)(cbase >> 8) * p.o_srows + pix) * 8 + ((cbase >> 5) & 7)] = (char)sbyte;
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        __syncthreads();
     }
 }
 
@@ -227,6 +287,12 @@ __global__ void __launch_bounds__(256) k_gconv_mx(GconvMxArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid = blockIdx.x;
+    {
+        // XCD-aware, bijective remap (workgroups b, b+8, ... share an XCD and its L2): each XCD takes a contiguous run of
+        // tiles, so neighbouring tiles share their halo in one L2
+        const int nwg = gridDim.x, xcd = bid & 7, local = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
     const int cchunk = bid % p.cchunks;
     bid /= p.cchunks;
     const int tx = bid % p.tiles_x;
@@ -437,6 +503,50 @@ int gconv_mfma_lds_bytes(int stride, int dil, int& th) {
     return ((in_th * in_tw + 7) / 8) * 1024;      // whole 8-pixel DMA groups
 }
 
+static int gconv_tile_bytes(int stride, int dil, int th) {
+    const int in_th = (th - 1) * stride + 2 * dil + 1, in_tw = (TW - 1) * stride + 2 * dil + 1;
+    return ((in_th * in_tw + 7) / 8) * 1024;
+}
+
+static int device_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// Tile height of the persistent kernel: two tile buffers must fit the CU's LDS, and among 8 and 4 (2 only when nothing else fits)
+// the one with the shortest schedule -- rounds of the slowest workgroup x (rows a round computes + a per-tile overhead): layers with
+// few tiles per workgroup lose less to the last, partly filled round and to the rows past the image with the lower tile
+// (measured at 1080p: layer4 88 -> 83 us, layer2 32 -> 30 us with 4 rows; layer1 ties and keeps 8).
+static int gconv_pick_th(const avl_seg_op& op, int comb, int cus, int* nsp_out, int* nslots_out) {
+    const int d = comb ? 1 : op.dil;
+    const int gh = comb ? (op.out_h + op.dil - 1) / op.dil : op.out_h, gw = comb ? (op.out_w + op.dil - 1) / op.dil : op.out_w;
+    const int ncomb = comb ? op.dil * op.dil : 1, cchunks = op.in_c / CC;
+    int best = 0;
+    double best_cost = 0.;
+    static const int env_th = getenv("AVL_GCONV_TH") ? atoi(getenv("AVL_GCONV_TH")) : 0;      // experiments
+    for (int th = 8; th >= 2; th >>= 1) {
+        if (2 * gconv_tile_bytes(op.stride, d, th) > 160 * 1024) continue;
+        const int nsp = ((gw + TW - 1) / TW) * ((gh + th - 1) / th) * ncomb;
+        int nslots = cus / cchunks;
+        if (nslots < 1) nslots = 1;
+        if (nslots > nsp) nslots = nsp;
+        const int rounds = (nsp + nslots - 1) / nslots;
+        const double cost = (double)rounds * (th + 0.5);
+        if (th == 2 && best != 0 && env_th != 2) break;
+        if (best == 0 || cost < best_cost || th == env_th) {
+            best = th; best_cost = th == env_th ? -1. : cost;
+            *nsp_out = nsp; *nslots_out = nslots;
+        }
+    }
+    return best;
+}
+
 template <typename HT, int WS>
 int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
     GconvArgs<HT> a;
@@ -456,14 +566,21 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
     a.H = op.in_h; a.W = op.in_w; a.in_ld = op.in_ld; a.OH = op.out_h; a.OW = op.out_w; a.out_ld = op.out_ld; a.C = op.in_c;
     a.stride = op.stride; a.dil = op.dil;
     a.comb = (op.stride == 1 && op.dil > 1 && op.pad == op.dil) ? 1 : 0;
-    const int ldsb = gconv_mfma_lds_bytes(op.stride, a.comb ? 1 : op.dil, a.th);
+    a.th = gconv_pick_th(op, a.comb, device_cus(), &a.nsp, &a.nslots);
+    a.tile_bytes = gconv_tile_bytes(op.stride, a.comb ? 1 : op.dil, a.th);
     const int gh = a.comb ? (op.out_h + op.dil - 1) / op.dil : op.out_h, gw = a.comb ? (op.out_w + op.dil - 1) / op.dil : op.out_w;
     a.tiles_x = (gw + TW - 1) / TW;
     a.tiles_y = (gh + a.th - 1) / a.th;
     a.cchunks = op.in_c / CC;
-    const int ncomb = a.comb ? op.dil * op.dil : 1;
-    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv_mfma<HT, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((k_gconv_mfma<HT, WS>), dim3(a.tiles_x * a.tiles_y * a.cchunks * ncomb), dim3(256), ldsb, s, a);
+#define AVL_GCONV_LAUNCH(NJ)                                                                                                          \
+    do {                                                                                                                              \
+        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv_mfma<HT, WS, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((k_gconv_mfma<HT, WS, NJ>), dim3(a.nslots * a.cchunks), dim3(512), 2 * a.tile_bytes, s, a);             \
+    } while (0)
+    if (a.th == 8) AVL_GCONV_LAUNCH(4);
+    else if (a.th == 4) AVL_GCONV_LAUNCH(2);
+    else AVL_GCONV_LAUNCH(1);
+#undef AVL_GCONV_LAUNCH
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
@@ -536,8 +653,7 @@ int validate_gconv_mfma(const avl_seg_op& op) {
     AVL_REQUIRE(!(op.mx_flags & AVL_MX_OUT_LO) || (op.out_mx && !op.out_lo), "grouped conv: AVL_MX_OUT_LO needs out_mx and no out_lo");
     const int cg = op.in_c / op.groups;
     AVL_REQUIRE(cg <= 32 && 32 % cg == 0, "MFMA grouped conv needs <= 32 channels per group dividing 32 (got %d)", cg);
-    int th;
-    AVL_REQUIRE(gconv_mfma_lds_bytes(op.stride, (op.stride == 1 && op.pad == op.dil) ? 1 : op.dil, th) <= 160 * 1024, "grouped conv tile does not fit LDS (dilation %d)", op.dil);
+    AVL_REQUIRE(2 * gconv_tile_bytes(op.stride, (op.stride == 1 && op.pad == op.dil) ? 1 : op.dil, 2) <= 160 * 1024, "grouped conv: two tile buffers do not fit LDS (dilation %d)", op.dil);
     return AVL_OK;
 }
 
