@@ -255,16 +255,20 @@ def fps_with_uploads(net, sm, cam, image_host, points_host, dev, steps, warmup):
     return round(steps / (time.perf_counter() - t0), 2)
 
 
-def _gpu_us_per_frame(fn, dev, reps=40):
+def _gpu_us_per_frame(fn, dev, reps=100):
     """GPU time of fn()'s kernels, back to back: the stream is first held busy (a few ms of large fills) so that the host
-    runs ahead and the launches queue up; HIP events bracket the reps on the launch stream (torch's current stream)."""
+    runs ahead and the launches queue up; HIP events bracket the reps on the launch stream (torch's current stream).  The fills
+    evict the grid from L2 / Infinity Cache, so a few untimed frames run between them and the first event (steady state, as in
+    the frame loop)."""
     import torch
     a = torch.empty(1 << 28, device=dev, dtype=torch.float32)          # 1 GiB: one fill ~0.3 ms
     fn()
     torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(20):
+    for _ in range(30):
         a.fill_(1.0)
+    for _ in range(10):
+        fn()
     e0.record()
     for _ in range(reps):
         fn()

@@ -208,6 +208,34 @@ def test_full_size_properties(cuda_device):
         assert np.array_equal(sm.map, grid)
 
 
+def test_dense_votes_in_one_sweep_round(cuda_device):
+    """A coarse grid under a dense cloud: 3377 voted cells land in ONE 16384-cell round of the byte-mask sweep (its LDS list is
+    sized for a fully voted round); the grid must still equal the oracle's bit for bit, frame after frame."""
+    import torch
+    from oracle import mapping_oracle as mo
+    from vision_semantic_segmentation_amd import synthetic as syn
+    from vision_semantic_segmentation_amd.camera import camera_setup_1
+    cam = camera_setup_1().scaled(1.0, 1080 / 1440.0)
+    rng = np.random.default_rng(7)
+    H, W = 1080, 1920
+    pcd = syn.make_cloud(rng, 400000, cam.K, cam.R, cam.t, W, H)
+    image = syn.colorize(syn.make_label_map(rng, H, W))
+    boundary = syn.centred_boundary(mo.PCD_ORIGIN_OFFSET[:2], 40.0)          # 80 m x 80 m at 0.5 m: 160 x 160 cells
+    cm = syn.log_confusion(5)
+    sm = make_sm(boundary, 0.5, cm, True, cuda_device)
+    img_d = torch.from_numpy(image).to(cuda_device)
+    grid = np.zeros((sm.map_height, sm.map_width, 5))
+    cfg = dict(range_max=100.0, boundary=boundary, resolution=0.5, label_names=mo.LABELS_NAMES,
+               label_colors=mo.LABEL_COLORS, confusion_matrix=cm, use_pcd_intensity=True)
+    for _ in range(2):
+        sm.frame_device(pcd, "velodyne", img_d, None, cam)
+        mo.mapping_frame(grid, pcd, "velodyne", image, None, cam.P, cfg)
+    voted = (grid != 0).any(axis=2).reshape(-1)
+    per_round = [int(voted[i:i + 16384].sum()) for i in range(0, voted.size, 16384)]
+    assert max(per_round) > 2048, "the cloud must crowd one round (voted cells per round: %r)" % (per_round,)
+    assert np.array_equal(sm.map, grid)
+
+
 def test_callbacks_and_replay(cuda_device, tmp_path):
     """The ROS-shaped path: pcd/pose/image callbacks with nearest-stamp matching (mapping.py:172-290), input
     recording, and the offline replay driver (mapping_replay.py:175-192) reproducing the same grid."""
