@@ -593,7 +593,13 @@ __device__ __forceinline__ unsigned quantize_fp4_block(const float (&v)[16], uns
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
-    amax = fmaxf(amax, __shfl_xor(amax, 16));
+    {
+        // partner = lane ^ 16, i.e. the neighbouring 16-lane row: v_permlane16_swap exchanges odd and even rows at VALU speed
+        // ([0] holds rows (0,0,2,2), [1] rows (1,1,3,3)); non-negative floats order as unsigned integers
+        const unsigned ab = __float_as_uint(amax);
+        const auto r16 = __builtin_amdgcn_permlane16_swap(ab, ab, false, false);
+        amax = __uint_as_float(max(r16[0], r16[1]));
+    }
     const unsigned e = __float_as_uint(amax) >> 23;
     const unsigned sbyte = e >= 3u ? e - 2u : 1u;            // 2^(floor(log2 amax) - 2): the block maximum lands in [4, 8) -> 4 or 6
     const float scale = __uint_as_float(sbyte << 23);
@@ -879,7 +885,9 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
                     unsigned pk[2];
                     const unsigned sb = quantize_fp4_block(pl == 0 ? hi : lo, pk);
                     // the block's 16 bytes (this lane's 8 + its partner's) leave through the even-kq lane as ONE store
-                    const unsigned p2 = __shfl_xor(pk[0], 16), p3 = __shfl_xor(pk[1], 16);
+                    // ([1] of the swap = the odd rows' values in both rows of a pair: what the even-kq lane needs)
+                    const unsigned p2 = __builtin_amdgcn_permlane16_swap(pk[0], pk[0], false, false)[1];
+                    const unsigned p3 = __builtin_amdgcn_permlane16_swap(pk[1], pk[1], false, false)[1];
                     if (live && (kq & 1) == 0) {
                         *reinterpret_cast<uint4*>(q.Cq[pl] + (long long)m * q.ldcq + nbase / 2) = make_uint4(pk[0], pk[1], p2, p3);
                         q.Cs[pl][((long long)(nbase >> 8) * q.c_srows + m) * 8 + ((nbase >> 5) & 7)] = (char)sb;
