@@ -370,6 +370,11 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtile
             const char* abase = lds + (ca % AST) * A_BYTES;
             const char* wbase = lds + (g % STAGES) * W_BYTES;
             if (PROBE == 1) { if (feed) issue_part(0, 1, jn); continue; }      // DMA only
+            // PROBE 2: LDS reads + MFMAs, no DMA;  PROBE 3: DMA + LDS reads, no MFMAs (timing experiments, results are garbage)
+            auto mm = [&](const v8& w_, const v8& a_, const f32x4& c_) -> f32x4 {
+                if constexpr (PROBE == 3) { asm volatile("" ::"v"(w_), "v"(a_)); return c_; }
+                else return Half16<H>::mfma(w_, a_, c_);
+            };
             auto rd_w = [&](int kk, int nj) { return *reinterpret_cast<const v8*>(wbase + w_off[nj] + (((kk * 4 + kq) ^ w_key[nj]) << 4)); };
             auto rd_a = [&](int kk, int mi) { return *reinterpret_cast<const v8*>(abase + a_off[mi] + (((kk * 4 + kq) ^ a_key[mi]) << 4)); };
             // The step is cut into 4 MFMA groups; the next stage's DMA instructions and the second K-half's fragment
@@ -380,7 +385,7 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtile
             // half in the middle, so that on every SIMD one wave is in an MFMA group while its partner pays the
             // (100+ cycle per instruction) LDS-DMA issue cost, instead of both doing the same thing at the same time.
             const bool early = MI == 8 && NW >= 8 && wave >= NW / 2;      // measured: +4-7 % on 256x256 tiles, -4 % on 256x128
-            if (feed && early) { issue_part(0, 2, jn); issue_part(1, 2, jn); }
+            if (feed && early && PROBE != 2) { issue_part(0, 2, jn); issue_part(1, 2, jn); }
             v8 wa[4], wb[4], af[MI];
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) wa[nj] = rd_w(0, nj);
@@ -390,25 +395,25 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtile
 #pragma unroll
             for (int mi = 0; mi < HALF; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<H>::mfma(wa[nj], af[mi], acc[mi][nj]);
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = mm(wa[nj], af[mi], acc[mi][nj]);
             __builtin_amdgcn_sched_barrier(0);
-            if (feed && !early) issue_part(0, 2, jn);
+            if (feed && !early && PROBE != 2) issue_part(0, 2, jn);
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) wb[nj] = rd_w(1, nj);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mi = HALF; mi < MI; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<H>::mfma(wa[nj], af[mi], acc[mi][nj]);
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = mm(wa[nj], af[mi], acc[mi][nj]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mi = 0; mi < HALF; ++mi) af[mi] = rd_a(1, mi);
-            if (feed && !early) issue_part(1, 2, jn);
+            if (feed && !early && PROBE != 2) issue_part(1, 2, jn);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mi = 0; mi < HALF; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<H>::mfma(wb[nj], af[mi], acc[mi][nj]);
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = mm(wb[nj], af[mi], acc[mi][nj]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mi = HALF; mi < MI; ++mi) af[mi] = rd_a(1, mi);
@@ -416,7 +421,7 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm_ring(GemmArgs p, int mtile
 #pragma unroll
             for (int mi = HALF; mi < MI; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<H>::mfma(wb[nj], af[mi], acc[mi][nj]);
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = mm(wb[nj], af[mi], acc[mi][nj]);
         }
         // ---- epilogue of tile t (the next tile's first stages are already in flight).  All residual loads
         // are issued before the first one is consumed, so their latency is paid once per tile, not per sub-tile.
@@ -511,9 +516,16 @@ int launch_ring(const GemmArgs& a0, int M, hipStream_t s) {
     const int total = mtiles * a.ntiles;
     const int grid = total < 256 ? total : 256;
     static const int probe = getenv("AVL_GEMM_PROBE") ? atoi(getenv("AVL_GEMM_PROBE")) : 0;   // timing experiments only
-    if (probe == 1 && NSUB == 1 && IO == 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<H, WM, WN, MI, STAGES, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        hipLaunchKernelGGL((k_gemm_ring<H, WM, WN, MI, STAGES, 1>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
+    if (probe >= 1 && probe <= 3 && NSUB == 1 && IO == 0) {
+#define AVL_PROBE_LAUNCH(P)                                                                                                                     \
+    do {                                                                                                                                        \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<H, WM, WN, MI, STAGES, P>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+        hipLaunchKernelGGL((k_gemm_ring<H, WM, WN, MI, STAGES, P>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);                         \
+    } while (0)
+        if (probe == 1) AVL_PROBE_LAUNCH(1);
+        else if (probe == 2) AVL_PROBE_LAUNCH(2);
+        else AVL_PROBE_LAUNCH(3);
+#undef AVL_PROBE_LAUNCH
     } else
         hipLaunchKernelGGL((k_gemm_ring<H, WM, WN, MI, STAGES, 0, NSUB, IO, AST>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
     AVL_LAUNCH_CHECK();
