@@ -584,6 +584,7 @@ struct MxArgs {
     const char* Aq2[2];
     const char* As2[2];
     long long a_srows2;
+    int stagger;                // 1: waves 0-3 issue their LDS-DMAs after the first K half of a sub-step (A/B switch)
 };
 
 __device__ __forceinline__ void glds16_saddr(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
@@ -738,6 +739,8 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
     if (vb < total) init_acc(vb);
 
     int g = 0;
+    static_assert(NW == 8, "the DMA stagger assumes waves w and w + 4 on one SIMD");
+    const int late = (wave >= 4 || q.stagger == 0) ? 0 : 1;       // the K half in front of which this wave issues its DMAs
     for (int t = vb; t < total; t += nwg) {
         const int nt = t % p.ntiles, mt = t / p.ntiles;
         // two plain loops per macro-block (f16 sub-steps, then FP4 sub-steps) rather than one loop with an if / else on the
@@ -746,11 +749,15 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
             for (int j = 0; j < 4; ++j, ++g) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // sub-step g has landed (this wave's share)
                 __builtin_amdgcn_s_barrier();
-                if (pt < total) issue();                                // sub-step g+1 -> the slots read during step g-1
+                // sub-step g+1 -> the slots read during step g-1.  Waves w and w + 4 share a SIMD: one issues its LDS-DMAs (100+
+                // cycles of issue each) at the head of the step, the other after its first K half, so that the SIMD's matrix pipe
+                // has one wave's MFMAs to run while the other is busy issuing (GEMMs 3.53 -> 3.40 ms per frame; spreading the
+                // instructions two at a time between MFMA groups instead: 4.0 ms)
                 const char* abase = lds + (g % STAGES) * A_BYTES + a_row0 * 128;
                 const char* wbase = lds + (g % STAGES) * W_BYTES;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
+                    if (kk == late && pt < total) issue();
                     v8 wf[4];
 #pragma unroll
                     for (int nj = 0; nj < 4; ++nj) wf[nj] = *reinterpret_cast<const v8*>(wbase + w_off[nj] + (((kk * 4 + kq) ^ w_key[nj]) << 4));
@@ -768,12 +775,12 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
             for (int u = 0; u < q.nmx; ++u, ++g) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (pt < total) issue();
                 const char* abase = lds + (g % STAGES) * A_BYTES + a_row0 * 128;
                 const char* wbase = lds + (g % STAGES) * W_BYTES;
                 const char* sbase = lds + (g % STAGES) * S_BYTES + S_REGION;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
+                    if (kk == late && pt < total) issue();
                     int4 wf[4];
                     int ws[4];
 #pragma unroll
@@ -915,6 +922,8 @@ template <int IO, int MI>
 int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
     constexpr int BM = 2 * MI * 16, LDS = 2 * (BM + 256) * 128 + 2 * 4096;
     MxArgs a = a0;
+    static const int stagger = getenv("AVL_MX_STAGGER") ? atoi(getenv("AVL_MX_STAGGER")) : 1;
+    a.stagger = stagger;
     a.g.ntiles = a.g.N / 256;
     const int mtiles = (a.g.M + BM - 1) / BM;
     const int total = mtiles * a.g.ntiles;
