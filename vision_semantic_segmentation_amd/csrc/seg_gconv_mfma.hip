@@ -117,6 +117,13 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
     // lane's 8 output channels: window base + q*8 + nj*4 + r
     const int cbase = c0 + win * 32 + kq * 8;
     const int chunk_in = win * 4 + kq;         // this lane's 16-byte chunk of the pixel row (8 input channels)
+    f32x4 bias0, bias1;
+    {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cbase);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cbase + 4);
+        bias0 = f32x4{b0.x, b0.y, b0.z, b0.w};
+        bias1 = f32x4{b1.x, b1.y, b1.z, b1.w};
+    }
 
     // the first tile has landed; zero what lies outside the image
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -130,6 +137,27 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
     zero_oob(oob, 0);
     __syncthreads();
 
+    // LDS byte offsets of the nine taps of each of this lane's sub-tiles: tile-invariant.  With one or two sub-tiles per wave
+    // they are kept in registers (9 x NJ); with four there is no room (256 VGPRs) and they are recomputed per tile.
+    constexpr bool HOIST = NJ <= 2;
+    int toff[HOIST ? NJ : 1][9];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int st = part + 4 * j;
+            const int sy = st >> 1, sx = (st & 1) * 16 + fr;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int pix = (sy * s + (t / 3) * d) * in_tw + sx * s + (t % 3) * d;
+                toff[j][t] = pix * 128 + ((chunk_in ^ (pix & 7)) << 4);
+            }
+        }
+    }
+    // output addressing in 32 bits off the (uniform) plane bases -- the epilogue is VALU-issue bound, 64-bit address chains cost
+    // as much as the arithmetic it is there for
+    const unsigned o_ld = (unsigned)p.out_ld, q_ld = (unsigned)(p.C / 2);
+    const unsigned sc_lane = (unsigned)(cbase >> 8) * (unsigned)p.o_srows * 8u + (unsigned)((cbase >> 5) & 7);
+
     // Per tile: [DMA of the next tile -> other buffer] [MFMA phase: this wave's sub-tiles, results stay in registers]
     // [s_waitcnt vmcnt(0): the next tile has landed -- the only older stores are those of the PREVIOUS tile, long retired, so
     // the wait never sits on fresh stores] [epilogue phase: bias, ReLU, hi/lo split, FP4 copies, stores] [barrier].
@@ -139,35 +167,31 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
         f32x4 acc[NJ][2];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int st = part + 4 * j;
-            int frv = fr;
-            asm volatile("" : "+v"(frv));       // the LDS addresses are tile-invariant: recompute them (a few VALU ops) rather than keep 9 x NJ of them in registers
-            const int sy = st >> 1, sx = (st & 1) * 16 + frv;        // output pixel (tile-local) of this lane
             // all nine tap fragments are requested before the first MFMA: the LDS latency is paid once per sub-tile
             v8 a[9];
+            if constexpr (HOIST) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) a[t] = *reinterpret_cast<const v8*>(tile + toff[j][t]);
+            } else {
+                const int st = part + 4 * j;
+                int frv = fr;
+                asm volatile("" : "+v"(frv));       // keeps hipcc from hoisting the 36 addresses (spills)
+                const int sy = st >> 1, sx = (st & 1) * 16 + frv;        // output pixel (tile-local) of this lane
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int pix = (sy * s + (t / 3) * d) * in_tw + sx * s + (t % 3) * d;
+                    a[t] = *reinterpret_cast<const v8*>(tile + pix * 128 + ((chunk_in ^ (pix & 7)) << 4));
+                }
+            }
+            // the accumulators start from the bias (the epilogue is VALU-issue bound next to the MFMAs: every op saved there counts)
+            f32x4 acc0 = bias0, acc1 = bias1;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int pix = (sy * s + (t / 3) * d) * in_tw + sx * s + (t % 3) * d;
-                a[t] = *reinterpret_cast<const v8*>(tile + pix * 128 + ((chunk_in ^ (pix & 7)) << 4));
-            }
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (WS != 0) {
-                // four independent accumulator chains (hi and lo weights apart): no MFMA waits for its predecessor
-                f32x4 acl0 = {0.f, 0.f, 0.f, 0.f}, acl1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    acc0 = Half16<HT>::mfma(wf[0][t], a[t], acc0);
-                    acc1 = Half16<HT>::mfma(wf[1][t], a[t], acc1);
-                    acl0 = Half16<HT>::mfma(wf[0][9 + t], a[t], acl0);
-                    acl1 = Half16<HT>::mfma(wf[1][9 + t], a[t], acl1);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { acc0[r] += acl0[r]; acc1[r] += acl1[r]; }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    acc0 = Half16<HT>::mfma(wf[0][t], a[t], acc0);
-                    acc1 = Half16<HT>::mfma(wf[1][t], a[t], acc1);
+                acc0 = Half16<HT>::mfma(wf[0][t], a[t], acc0);
+                acc1 = Half16<HT>::mfma(wf[1][t], a[t], acc1);
+                if constexpr (WS != 0) {
+                    acc0 = Half16<HT>::mfma(wf[0][9 + t], a[t], acc0);
+                    acc1 = Half16<HT>::mfma(wf[1][9 + t], a[t], acc1);
                 }
             }
             acc[j][0] = acc0; acc[j][1] = acc1;
@@ -180,27 +204,20 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
         const int ty = r1 % p.tiles_y, cmb = r1 / p.tiles_y;
         const int ry = p.comb ? cmb / p.dil : 0, rx = p.comb ? cmb % p.dil : 0;
         const int oy0 = ty * p.th, ox0 = tx * TW;    // tile origin on its grid
-        float bias[8];
-        {
-            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cbase);
-            const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cbase + 4);
-            bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
-            bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
-        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int st = part + 4 * j;
             const int sy = st >> 1, sx = (st & 1) * 16 + fr;
             const int oy = ry + (oy0 + sy) * step, ox = rx + (ox0 + sx) * step;
             const bool live = oy < p.OH && ox < p.OW;
-            const long long pix = live ? (long long)oy * p.OW + ox : 0;
+            const unsigned pix = live ? (unsigned)oy * (unsigned)p.OW + (unsigned)ox : 0u;
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[r] = fmaxf(acc[j][0][r] + bias[r], 0.f);
-                v[4 + r] = fmaxf(acc[j][1][r] + bias[4 + r], 0.f);
+                v[r] = fmaxf(acc[j][0][r], 0.f);
+                v[4 + r] = fmaxf(acc[j][1][r], 0.f);
             }
-            if (live) Vec8<HT>::store(p.out + pix * p.out_ld + cbase, v);
+            if (live) Vec8<HT>::store(p.out + (pix * o_ld + (unsigned)cbase), v);
             if constexpr (WS != 0) {
                 float lo[8];
 #pragma unroll
@@ -210,7 +227,7 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
                     if (p.out_lo) lo[r] = (float)(HT)lo[r];        // a stored lo plane is f16: its FP4 copy is taken from what it holds
                     v[r] = h;
                 }
-                if (p.out_lo && live) Vec8<HT>::store(p.out_lo + pix * p.out_ld + cbase, lo);
+                if (p.out_lo && live) Vec8<HT>::store(p.out_lo + (pix * o_ld + (unsigned)cbase), lo);
                 // FP4 copies: the window's 32 channels (the four kq lanes of this pixel) are one MX block.  The four lanes sit
                 // 16 apart: v_permlane16_swap / v_permlane32_swap exchange them at VALU speed (no LDS round trip).
 #pragma unroll
@@ -235,13 +252,11 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
                     pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[2], src[3], scale, 1);
                     pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[4], src[5], scale, 2);
                     pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[6], src[7], scale, 3);
-                    // the window's 16 bytes leave through its kq = 0 lane as ONE store: row 0 collects rows 1, 2, 3
-                    const auto g16 = __builtin_amdgcn_permlane16_swap(pk, pk, false, false);           // [1]: rows (1,1,3,3)
-                    const auto g32 = __builtin_amdgcn_permlane32_swap(pk, pk, false, false);           // [1]: rows (2,3,2,3)
-                    const auto g48 = __builtin_amdgcn_permlane32_swap(g16[1], g16[1], false, false);   // [1]: rows (3,3,3,3)
-                    if (kq == 0 && live) {
-                        *reinterpret_cast<uint4*>(p.oq[pl] + pix * (p.C / 2) + cbase / 2) = make_uint4(pk, g16[1], g32[1], g48[1]);
-                        p.os[pl][((long long)(cbase >> 8) * p.o_srows + pix) * 8 + ((cbase >> 5) & 7)] = (char)sbyte;
+                    // every lane stores its own 4 bytes (the window's four lanes fill 16 contiguous bytes); the scale byte leaves
+                    // through the kq = 0 lane
+                    if (live) {
+                        *reinterpret_cast<unsigned*>(p.oq[pl] + (pix * q_ld + (unsigned)(cbase / 2))) = pk;
+                        if (kq == 0) p.os[pl][sc_lane + pix * 8u] = (char)sbyte;
                     }
                 }
             }
@@ -651,6 +666,8 @@ int validate_gconv_mfma(const avl_seg_op& op) {
     }
     AVL_REQUIRE(!op.out_mx || (op.w_split >= 1 && op.out_c % 256 == 0 && op.out_ld == op.out_c), "grouped conv: out_mx needs w_split, channels %% 256 == 0 and a dense output");
     AVL_REQUIRE(!(op.mx_flags & AVL_MX_OUT_LO) || (op.out_mx && !op.out_lo), "grouped conv: AVL_MX_OUT_LO needs out_mx and no out_lo");
+    AVL_REQUIRE((long long)op.out_rows * op.out_ld * 2 < (1LL << 31) && (long long)(op.out_c / 256 + 1) * op.out_rows * 8 < (1LL << 31),
+                "grouped conv: output planes beyond 2 GB (32-bit epilogue addressing)");
     const int cg = op.in_c / op.groups;
     AVL_REQUIRE(cg <= 32 && 32 % cg == 0, "MFMA grouped conv needs <= 32 channels per group dividing 32 (got %d)", cg);
     AVL_REQUIRE(2 * gconv_tile_bytes(op.stride, (op.stride == 1 && op.pad == op.dil) ? 1 : op.dil, 2) <= 160 * 1024, "grouped conv: two tile buffers do not fit LDS (dilation %d)", op.dil);
