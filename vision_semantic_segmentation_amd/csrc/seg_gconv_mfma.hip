@@ -39,6 +39,7 @@ struct GconvArgs {
     int comb;            // 1: stride 1, dilation d > 1 -> tiles live on the d x d residue-class grids (see below)
     int nsp, nslots;     // pixel tiles (all residue classes), and how many of them are in flight (workgroups per channel chunk)
     int tile_bytes;      // one LDS tile buffer
+    int tw_magic;        // ceil(65536 / input tile width): pix / in_tw == (pix * tw_magic) >> 16 for every pixel of a tile
 };
 
 // WS = 1 ("mixed" precision): the weights come as f16 pairs hi + lo ([window][nj 2][tap 18 = 9 hi, 9 lo][16][32]); both
@@ -87,12 +88,13 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
         int it = 0;
         for (int gi = wave; gi < ngroups; gi += 8, ++it) {
             const int pix = gi * 8 + prow;
-            const int ly = pix / in_tw, lx = pix - ly * in_tw;
+            const int ly = (pix * p.tw_magic) >> 16, lx = pix - ly * in_tw;     // pix / in_tw (exact for the tile sizes: checked on the host)
             const int iy = iy0 + ly * step, ix = ix0 + lx * step;
             const bool inside = pix < npix && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-            const HT* src = p.in + ((long long)cy * p.W + cx) * p.in_ld + c0 + ((cphys ^ (pix & 7)) << 3);
-            glds16_asm(src, lds0 + buf * p.tile_bytes + gi * 1024);
+            // uniform base (plane + channel chunk) + 32-bit lane offset
+            const unsigned voff = ((unsigned)(cy * p.W + cx) * (unsigned)p.in_ld + ((cphys ^ (pix & 7)) << 3)) * (unsigned)sizeof(HT);
+            glds16_saddr(p.in + c0, voff, lds0 + buf * p.tile_bytes + gi * 1024);
             oob |= (inside ? 0u : 1u) << it;
         }
         return oob;
@@ -583,6 +585,13 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
     a.comb = (op.stride == 1 && op.dil > 1 && op.pad == op.dil) ? 1 : 0;
     a.th = gconv_pick_th(op, a.comb, device_cus(), &a.nsp, &a.nslots);
     a.tile_bytes = gconv_tile_bytes(op.stride, a.comb ? 1 : op.dil, a.th);
+    {
+        const int d = a.comb ? 1 : op.dil;
+        const int in_th = (a.th - 1) * op.stride + 2 * d + 1, in_tw = (TW - 1) * op.stride + 2 * d + 1;
+        a.tw_magic = (65536 + in_tw - 1) / in_tw;
+        for (int pix = 0; pix < ((in_th * in_tw + 7) / 8) * 8; ++pix)
+            AVL_REQUIRE(((pix * a.tw_magic) >> 16) == pix / in_tw, "grouped conv: tile %d x %d too large for the reciprocal division", in_th, in_tw);
+    }
     const int gh = a.comb ? (op.out_h + op.dil - 1) / op.dil : op.out_h, gw = a.comb ? (op.out_w + op.dil - 1) / op.dil : op.out_w;
     a.tiles_x = (gw + TW - 1) / TW;
     a.tiles_y = (gh + a.th - 1) / a.th;
@@ -666,6 +675,7 @@ int validate_gconv_mfma(const avl_seg_op& op) {
     }
     AVL_REQUIRE(!op.out_mx || (op.w_split >= 1 && op.out_c % 256 == 0 && op.out_ld == op.out_c), "grouped conv: out_mx needs w_split, channels %% 256 == 0 and a dense output");
     AVL_REQUIRE(!(op.mx_flags & AVL_MX_OUT_LO) || (op.out_mx && !op.out_lo), "grouped conv: AVL_MX_OUT_LO needs out_mx and no out_lo");
+    AVL_REQUIRE((long long)op.in_rows * op.in_ld * 2 < (1LL << 31), "grouped conv: input plane beyond 2 GB (32-bit DMA offsets)");
     AVL_REQUIRE((long long)op.out_rows * op.out_ld * 2 < (1LL << 31) && (long long)(op.out_c / 256 + 1) * op.out_rows * 8 < (1LL << 31),
                 "grouped conv: output planes beyond 2 GB (32-bit epilogue addressing)");
     const int cg = op.in_c / op.groups;

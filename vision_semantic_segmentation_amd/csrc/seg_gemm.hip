@@ -587,19 +587,6 @@ struct MxArgs {
     int stagger;                // 1: waves 0-3 issue their LDS-DMAs after the first K half of a sub-step (A/B switch)
 };
 
-__device__ __forceinline__ void glds16_saddr(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
-        : "memory");
-}
-
 // 16 values of one lane + the 16 of its partner (lane ^ 16) form one MX block: shared E8M0 scale, e2m1 elements.
 // Returns the scale byte; q[0..1] = the lane's 16 values packed (element 2i in the low nibble of byte i).
 __device__ __forceinline__ unsigned quantize_fp4_block(const float (&v)[16], unsigned (&q)[2]) {

@@ -105,6 +105,20 @@ __device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_byte_addr
         : "memory");
 }
 
+// The same with an SGPR base and a 32-bit VGPR byte offset (the tile / plane base is uniform, the lane keeps only its offset).
+__device__ __forceinline__ void glds16_saddr(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+        : "memory");
+}
+
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
