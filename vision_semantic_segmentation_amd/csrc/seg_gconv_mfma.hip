@@ -219,17 +219,30 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
                 v[r] = fmaxf(acc[j][0][r], 0.f);
                 v[4 + r] = fmaxf(acc[j][1][r], 0.f);
             }
-            if (live) Vec8<HT>::store(p.out + (pix * o_ld + (unsigned)cbase), v);
-            if constexpr (WS != 0) {
+            if constexpr (WS == 0) {
+                if (live) Vec8<HT>::store(p.out + (pix * o_ld + (unsigned)cbase), v);
+            } else {
+                // ONE conversion to the 16-bit type: the packed vector is what gets stored AND what hi is read back from
+                typedef typename Half16<HT>::v8 h8;
+                h8 hv;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) hv[r] = (HT)v[r];
+                if (live) *reinterpret_cast<h8*>(p.out + (pix * o_ld + (unsigned)cbase)) = hv;
                 float lo[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const float h = (float)(HT)v[r];
+                    const float h = (float)hv[r];
                     lo[r] = v[r] - h;
-                    if (p.out_lo) lo[r] = (float)(HT)lo[r];        // a stored lo plane is f16: its FP4 copy is taken from what it holds
                     v[r] = h;
                 }
-                if (p.out_lo && live) Vec8<HT>::store(p.out_lo + (pix * o_ld + (unsigned)cbase), lo);
+                if (p.out_lo) {        // a stored lo plane is f16: its FP4 copy is taken from what it holds
+                    h8 lv;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) lv[r] = (HT)lo[r];
+                    if (live) *reinterpret_cast<h8*>(p.out_lo + (pix * o_ld + (unsigned)cbase)) = lv;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) lo[r] = (float)lv[r];
+                }
                 // FP4 copies: the window's 32 channels (the four kq lanes of this pixel) are one MX block.  The four lanes sit
                 // 16 apart: v_permlane16_swap / v_permlane32_swap exchange them at VALU speed (no LDS round trip).
 #pragma unroll
