@@ -801,28 +801,34 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
         const int nbase = nt * BN + wn * 64 + kq * 16;
         const bool ncol_ok = nbase + 16 <= p.N;
         const bool rsplit = p.R_lo != nullptr, csplit = p.C_lo != nullptr;
+        // The epilogue is VALU-issue bound (eight rounds of ~250 vector instructions per wave while the matrix pipe idles), so:
+        // every address is a 32-bit offset from a uniform plane base (validate_gemm bounds the planes to 2 GB), the result is
+        // converted to f16 ONCE (the packed vector is stored and read back as hi), every lane stores its own 8 FP4 bytes.
+        const unsigned m0 = (unsigned)(mt * BM + wm * (MI * 16) + fr);
+        const unsigned sc_r = (unsigned)(nbase >> 8) * (unsigned)q.r_srows * 8u + (unsigned)((nbase >> 5) & 7);
+        const unsigned sc_c = (unsigned)(nbase >> 8) * (unsigned)q.c_srows * 8u + (unsigned)((nbase >> 5) & 7);
         // the residual of row mi + 1 is requested before row mi is worked on (its loads could otherwise not move above row
         // mi's stores, and eight dependent load -> compute -> store rounds cost more than the K loop of a short-K tile)
         v8 nr0 = {}, nr1 = {};
         uint2 npk = make_uint2(0u, 0u);
         unsigned nsb = 127u;
         auto load_res = [&](int mi) {
-            const int m = mt * BM + wm * (MI * 16) + mi * 16 + fr;
-            if (p.R && m < p.M && ncol_ok) {
-                const H* rp = static_cast<const H*>(p.R) + (long long)m * p.ldr + nbase;
+            const unsigned m = m0 + mi * 16;
+            if (p.R && (int)m < p.M && ncol_ok) {
+                const H* rp = static_cast<const H*>(p.R) + (m * (unsigned)p.ldr + (unsigned)nbase);
                 nr0 = *reinterpret_cast<const v8*>(rp);
                 nr1 = *reinterpret_cast<const v8*>(rp + 8);
                 if (q.Rq) {       // the lo part as FP4: 16 values = 8 bytes, one scale byte for the lane pair's 32-block
-                    npk = *reinterpret_cast<const uint2*>(q.Rq + (long long)m * q.ldrq + nbase / 2);
-                    nsb = (unsigned char)q.Rs[((long long)(nbase >> 8) * q.r_srows + m) * 8 + ((nbase >> 5) & 7)];
+                    npk = *reinterpret_cast<const uint2*>(q.Rq + (m * (unsigned)q.ldrq + (unsigned)(nbase / 2)));
+                    nsb = (unsigned char)q.Rs[sc_r + m * 8u];
                 }
             }
         };
         load_res(0);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const int m = mt * BM + wm * (MI * 16) + mi * 16 + fr;
-            const bool live = m < p.M && ncol_ok;
+            const unsigned m = m0 + mi * 16;
+            const bool live = (int)m < p.M && ncol_ok;
             const v8 r0 = nr0, r1 = nr1;
             const uint2 pk = npk;
             const unsigned sb = nsb;
@@ -837,7 +843,7 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) rl[i] = 0.f;
                 if (rsplit) {
-                    const H* rlp = static_cast<const H*>(p.R_lo) + (long long)m * p.ldr + nbase;
+                    const H* rlp = static_cast<const H*>(p.R_lo) + (m * (unsigned)p.ldr + (unsigned)nbase);
                     const v8 l0 = *reinterpret_cast<const v8*>(rlp), l1 = *reinterpret_cast<const v8*>(rlp + 8);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { rl[i] = (float)l0[i]; rl[8 + i] = (float)l1[i]; }
@@ -857,46 +863,46 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
             }
+            v8 h0, h1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { h0[i] = (H)v[i]; h1[i] = (H)v[8 + i]; }
             float hi[16], lo[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                hi[i] = (float)(H)v[i];
+            for (int i = 0; i < 8; ++i) {
+                hi[i] = (float)h0[i];
+                hi[8 + i] = (float)h1[i];
                 lo[i] = v[i] - hi[i];
-                if (csplit) lo[i] = (float)(H)lo[i];          // a stored lo plane is f16: its FP4 copy is taken from what it holds
+                lo[8 + i] = v[8 + i] - hi[8 + i];
             }
+            const unsigned coff = m * (unsigned)p.ldc + (unsigned)nbase;
             if (live) {
-                H* cp = static_cast<H*>(p.C) + (long long)m * p.ldc + nbase;
-                float a8[8], b8[8];
+                H* cp = static_cast<H*>(p.C) + coff;
+                *reinterpret_cast<v8*>(cp) = h0;
+                *reinterpret_cast<v8*>(cp + 8) = h1;
+            }
+            if (csplit) {          // a stored lo plane is f16: its FP4 copy is taken from what it holds
+                v8 l0, l1;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { a8[i] = hi[i]; b8[i] = hi[8 + i]; }
-                Vec8<H>::store(cp, a8);
-                Vec8<H>::store(cp + 8, b8);
-                if (csplit) {
-                    H* cl = static_cast<H*>(p.C_lo) + (long long)m * p.ldc + nbase;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { a8[i] = lo[i]; b8[i] = lo[8 + i]; }
-                    Vec8<H>::store(cl, a8);
-                    Vec8<H>::store(cl + 8, b8);
+                for (int i = 0; i < 8; ++i) { l0[i] = (H)lo[i]; l1[i] = (H)lo[8 + i]; }
+                if (live) {
+                    H* cl = static_cast<H*>(p.C_lo) + coff;
+                    *reinterpret_cast<v8*>(cl) = l0;
+                    *reinterpret_cast<v8*>(cl + 8) = l1;
                 }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { lo[i] = (float)l0[i]; lo[8 + i] = (float)l1[i]; }
             }
             if constexpr (IO != 0) {
-                // every lane takes part in the shuffles (rows past M quantise zeros and store nothing)
-                if (!live) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) hi[i] = lo[i] = 0.f;
-                }
+                // every lane takes part in the block exchange; rows past M quantise whatever they hold and store nothing
+                // (the partner lane is the same row, so it is dead as well)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
                     if (q.Cq[pl] == nullptr) continue;
-                    unsigned pk[2];
-                    const unsigned sb = quantize_fp4_block(pl == 0 ? hi : lo, pk);
-                    // the block's 16 bytes (this lane's 8 + its partner's) leave through the even-kq lane as ONE store
-                    // ([1] of the swap = the odd rows' values in both rows of a pair: what the even-kq lane needs)
-                    const unsigned p2 = __builtin_amdgcn_permlane16_swap(pk[0], pk[0], false, false)[1];
-                    const unsigned p3 = __builtin_amdgcn_permlane16_swap(pk[1], pk[1], false, false)[1];
-                    if (live && (kq & 1) == 0) {
-                        *reinterpret_cast<uint4*>(q.Cq[pl] + (long long)m * q.ldcq + nbase / 2) = make_uint4(pk[0], pk[1], p2, p3);
-                        q.Cs[pl][((long long)(nbase >> 8) * q.c_srows + m) * 8 + ((nbase >> 5) & 7)] = (char)sb;
+                    unsigned pq[2];
+                    const unsigned sq = quantize_fp4_block(pl == 0 ? hi : lo, pq);
+                    if (live) {
+                        *reinterpret_cast<uint2*>(q.Cq[pl] + (m * (unsigned)q.ldcq + (unsigned)(nbase / 2))) = make_uint2(pq[0], pq[1]);
+                        if ((kq & 1) == 0) q.Cs[pl][sc_c + m * 8u] = (char)sq;
                     }
                 }
             }
@@ -977,6 +983,8 @@ int validate_gemm(const avl_seg_op& op) {
             AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.in3) | reinterpret_cast<uintptr_t>(op.in3_mx)) % 16 == 0, "second GEMM input must be 16-byte aligned");
         }
         AVL_REQUIRE((long long)op.in_rows * K * 2 < 0xffffff00LL && (long long)op.w_rows * K * 2 < 0xffffff00LL, "MX GEMM operand larger than 4 GB");
+        AVL_REQUIRE((long long)op.out_rows * op.out_ld * 2 < (1LL << 31) && (!op.in2 || (long long)op.out_rows * op.in2_ld * 2 < (1LL << 31)) &&
+                    (long long)(N / 256 + 1) * op.out_rows * 8 < (1LL << 31), "MX GEMM output / residual plane beyond 2 GB (32-bit epilogue addressing)");
         AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.w_mx) | reinterpret_cast<uintptr_t>(op.in_mx) | reinterpret_cast<uintptr_t>(op.out_mx) |
                      reinterpret_cast<uintptr_t>(op.in_lo) | reinterpret_cast<uintptr_t>(op.in2_lo) | reinterpret_cast<uintptr_t>(op.out_lo)) % 16 == 0,
                     "MX GEMM bundles / low planes must be 16-byte aligned");
