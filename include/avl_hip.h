@@ -83,8 +83,12 @@ typedef struct avl_grid {
     uint32_t* cell_mask;  /* scratch uint32[Hm*Wm]; all zero on entry, all zero again on return   */
     int32_t* touched;     /* scratch int32[touched_cap]: cells first touched this frame           */
     int32_t touched_cap;  /* >= min(n points, Hm*Wm)                                              */
-    int32_t* counter;     /* scratch int32[4] (16-byte block of its own); zeroed by the call      */
+    int32_t* counter;     /* scratch int32[counter_len] (a block of its own); ints [0,4) are zeroed by the
+                             calls that use them, ints [4, counter_len) must be zero on entry and are zero
+                             again on return (per-list cursors of the partitioned touched lists)      */
+    int32_t counter_len;  /* >= 4; >= AVL_COUNTER_INTS enables the partitioned lists of avl_fused_frame   */
 } avl_grid;
+#define AVL_COUNTER_INTS 256
 
 /* update_map for points that already carry an RGB label (the reference's own signature).
  * pcd double[4][ld] (rows x,y,z,intensity), label uint8[3][ld]; the number of points is m_host,

@@ -197,6 +197,8 @@ def test_full_size_properties(cuda_device):
                    label_colors=mo.LABEL_COLORS, confusion_matrix=cm, use_pcd_intensity=True)
         mo.mapping_frame(grid, pcd, "velodyne", image, None, cam.P, cfg)
         assert np.array_equal(one.cpu().numpy(), grid)
+        # scratch is clean again: vote mask all zero, list cursors and tickets of the partitioned lists back to zero
+        assert not bool(sm.grid.cell_mask.any()) and not bool(sm.grid.counter[4:].any())
         # duplicated + permuted cloud gives the same single-frame delta
         sm.map = np.zeros_like(grid)
         perm = rng.permutation(2 * n)

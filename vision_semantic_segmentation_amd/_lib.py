@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("AVL_HIP_LIB", os.path.join(_HERE, "libavl_hip.so"))  
 AVL_F32, AVL_F64, AVL_BF16, AVL_F16 = 0, 1, 2, 3
 AVL_SRC_RGB, AVL_SRC_CLASSMAP = 0, 1
 AVL_MAX_MAP_CLASSES = 16
+AVL_COUNTER_INTS = 256          # avl_grid.counter block (include/avl_hip.h)
 
 _lib = None
 _lock = threading.Lock()
@@ -25,6 +26,7 @@ class AvlGrid(C.Structure):
         ("off_x", C.c_double), ("off_y", C.c_double), ("b00", C.c_double), ("b10", C.c_double),
         ("resolution", C.c_double),
         ("cell_mask", C.c_void_p), ("touched", C.c_void_p), ("touched_cap", C.c_int32), ("counter", C.c_void_p),
+        ("counter_len", C.c_int32),
     ]
 
 

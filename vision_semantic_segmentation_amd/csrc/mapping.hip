@@ -280,12 +280,43 @@ __global__ void __launch_bounds__(kBlock) k_vote_labelled(const double* __restri
 }
 
 // ---------------------------------------------------------------- fused project + vote
-// MODE: 0 = 32-bit mask + touched list, 1 = 32-bit mask only (sweep), 2 = byte mask only (sweep, see encode_vote_byte)
+// Partitioned touched lists (MODE 3).  The single-counter list of cast_vote serialises on one L2 address (185 us for the 1 M
+// points of config E); here a workgroup compacts its first-touch cells in LDS, reserves their range with ONE global atomic on
+// counter kListBase + (workgroup % kLists) and appends to that list: 64 addresses, ~60 atomics each.  List k holds at most
+// (workgroups of k) x 256 entries, so `cap` = ceil(nwg / kLists) * 256 never overflows.
+constexpr int kLists = 64;
+constexpr int kListBase = 4;                 // counter[4 .. 4 + kLists): cursors; counter[4 + kLists .. 4 + 2 kLists): apply tickets
+__device__ __forceinline__ void cast_vote_byte_lists(unsigned* cell_mask, int* touched, int* counter, int cap, int cell, unsigned vote,
+                                                     int C, unsigned bonus_classes) {
+    __shared__ int wg_count, wg_base;
+    if (threadIdx.x == 0) wg_count = 0;
+    __syncthreads();
+    bool first = false;
+    if (cell >= 0 && vote != 0) {
+        const unsigned enc = encode_vote_byte(vote, C, bonus_classes);
+        const unsigned sh = 8u * ((unsigned)cell & 3u);
+        const unsigned old = atomicOr(&cell_mask[cell >> 2], enc << sh);
+        first = ((old >> sh) & 0xffu) == 0u;          // this lane turned the cell's byte non-zero: it lists the cell
+    }
+    const unsigned long long m = __ballot(first);
+    const int lane = threadIdx.x & 63;
+    int wave_off = 0;
+    if (m != 0ull && lane == 0) wave_off = atomicAdd(&wg_count, __builtin_popcountll(m));
+    wave_off = __shfl(wave_off, 0);
+    __syncthreads();
+    const int list = blockIdx.x % kLists;
+    if (threadIdx.x == 0 && wg_count > 0) wg_base = atomicAdd(&counter[kListBase + list], wg_count);
+    __syncthreads();
+    if (first) touched[(long long)list * cap + wg_base + wave_off + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = cell;
+}
+
+// MODE: 0 = 32-bit mask + touched list, 1 = 32-bit mask only (sweep), 2 = byte mask only (sweep, see encode_vote_byte),
+//       3 = byte mask + partitioned touched lists (k_grid_apply_lists)
 template <int SRC, int MODE>
 __global__ void __launch_bounds__(kBlock) k_fused_vote(PtsView pv, ProjParams pp, GridParams g,
                                                        const unsigned char* __restrict__ src, int src_w, int src_h,
                                                        LutParams lut, unsigned* __restrict__ cell_mask,
-                                                       int* __restrict__ touched, int* __restrict__ counter) {
+                                                       int* __restrict__ touched, int* __restrict__ counter, int list_cap) {
     const int k = blockIdx.x * kBlock + threadIdx.x;
     int cell = -1;
     unsigned vote = 0;
@@ -312,7 +343,8 @@ __global__ void __launch_bounds__(kBlock) k_fused_vote(PtsView pv, ProjParams pp
     }
     if (MODE == 0) cast_vote(cell_mask, touched, counter, cell, vote);
     else if (MODE == 1) cast_vote_nolist(cell_mask, cell, vote);
-    else cast_vote_byte(cell_mask, cell, vote, g.C, g.bonus_classes);
+    else if (MODE == 2) cast_vote_byte(cell_mask, cell, vote, g.C, g.bonus_classes);
+    else cast_vote_byte_lists(cell_mask, touched, counter, list_cap, cell, vote, g.C, g.bonus_classes);
 }
 
 // ---------------------------------------------------------------- touched cells -> grid (:424,437)
@@ -371,6 +403,55 @@ __global__ void __launch_bounds__(kBlock) k_grid_apply_scan(MapT* __restrict__ m
             }
         }
         reinterpret_cast<uint4*>(cell_mask)[q] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+// Partitioned lists -> grid (MODE 3 of k_fused_vote).  Workgroup (list k, slice j) applies entries j*256 + lane, + W*256, ... of
+// list k: reads the cell's vote byte, clears it, updates the row in the reference's class order.  The last workgroup of a list
+// to finish (a ticket per list: 64 addresses again) zeroes the list's cursor and ticket, so the counters are all zero on return.
+template <typename MapT>
+__global__ void __launch_bounds__(kBlock) k_grid_apply_lists(MapT* __restrict__ map, int C, unsigned bonus_classes, CmParams cm,
+                                                             unsigned char* __restrict__ mask, const int* __restrict__ touched,
+                                                             int* __restrict__ counter, int cap, int wgs_per_list) {
+    const int k = blockIdx.x % kLists, j = blockIdx.x / kLists;
+    const int n = counter[kListBase + k];
+    const int* list = touched + (long long)k * cap;
+    for (int e = j * kBlock + threadIdx.x; e < n; e += wgs_per_list * kBlock) {
+        const int cell = list[e];
+        const unsigned m = mask[cell];
+        mask[cell] = 0;
+        MapT* row = map + (long long)cell * C;
+        double vals[AVL_MAX_MAP_CLASSES];
+#pragma unroll
+        for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
+            if (c < C) vals[c] = (double)row[c];
+        int r = 0;
+        for (int i = 0; i < C; ++i) {
+            if (m & (1u << i)) {
+#pragma unroll
+                for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
+                    if (c < C) vals[c] = (double)(MapT)(vals[c] + cm.cm[c * C + i]);
+            }
+            if ((bonus_classes >> i) & 1u) {
+                if (m & (1u << (C + r))) {
+#pragma unroll
+                    for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
+                        if (c == i) vals[c] = (double)(MapT)(vals[c] + 2.0);
+                }
+                ++r;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
+            if (c < C) row[c] = (MapT)vals[c];
+    }
+    __syncthreads();                  // every lane of this workgroup has read n
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(&counter[kListBase + kLists + k], 1);
+        if (t == wgs_per_list - 1) {
+            counter[kListBase + k] = 0;
+            counter[kListBase + kLists + k] = 0;
+        }
     }
 }
 
@@ -674,6 +755,45 @@ bool byte_mask_ok(const avl_grid* g, unsigned bonus) {
     return g->C + __builtin_popcount(bonus) <= 8 && cells % 16 == 0 && (reinterpret_cast<uintptr_t>(g->cell_mask) & 15) == 0;
 }
 
+// partitioned lists: geometry shared by the vote and the apply launch
+struct ListGeom { int cap, wgs_per_list, apply_wgs; };
+ListGeom list_geom(int n) {
+    ListGeom lg;
+    const int nwg = (n + kBlock - 1) / kBlock;
+    const int per = (nwg + kLists - 1) / kLists;                 // vote workgroups per list
+    lg.cap = per * kBlock;
+    lg.wgs_per_list = per < 16 ? per : 16;                       // apply workgroups per list (grid-stride over the list)
+    lg.apply_wgs = lg.wgs_per_list * kLists;
+    return lg;
+}
+// MODE 3 needs the big counter block, room for kLists x cap entries and a byte mask.  Its cost grows with the cloud (returning
+// atomics in the vote, rows visited in point order -- no locality -- in the apply), the sweep's is ~15 us whatever the cloud:
+// measured 17 vs 22 us per frame at 120 k points on 4 M cells (config C), 54 vs 38 us at 1 M points on 16 M cells (config E).
+// AVL_APPLY_MODE=plist forces it (experiments).
+bool use_lists(const avl_grid* g, int n, unsigned bonus) {
+    static const char* mode = getenv("AVL_APPLY_MODE");
+    if (g->counter_len < kListBase + 2 * kLists || !byte_mask_ok(g, bonus)) return false;
+    if ((long long)list_geom(n).cap * kLists > g->touched_cap) return false;
+    if (mode && mode[0] == 'p') return true;
+    if (mode) return false;
+    return n <= 250000 && (long long)n * 2 <= (long long)g->Hm * g->Wm;
+}
+int launch_apply_lists(const avl_grid* g, const double* cm_host, unsigned bonus, int n, hipStream_t s) {
+    CmParams cm;
+    memset(&cm, 0, sizeof(cm));
+    for (int i = 0; i < g->C * g->C; ++i) cm.cm[i] = cm_host[i];
+    const ListGeom lg = list_geom(n);
+    unsigned char* mask = reinterpret_cast<unsigned char*>(g->cell_mask);
+    if (g->map_dtype == AVL_F64)
+        hipLaunchKernelGGL(k_grid_apply_lists<double>, dim3(lg.apply_wgs), dim3(kBlock), 0, s, static_cast<double*>(g->map), g->C, bonus, cm,
+                           mask, g->touched, g->counter, lg.cap, lg.wgs_per_list);
+    else
+        hipLaunchKernelGGL(k_grid_apply_lists<float>, dim3(lg.apply_wgs), dim3(kBlock), 0, s, static_cast<float*>(g->map), g->C, bonus, cm,
+                           mask, g->touched, g->counter, lg.cap, lg.wgs_per_list);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
 // list (sparse) vs sweep (dense) apply: the sweep reads Hm*Wm*4 bytes whatever the cloud; the list costs a
 // returning atomic + an append per first touch.  AVL_APPLY_MODE=list|scan overrides (experiments).
 bool use_scan(const avl_grid* g, int n) {
@@ -805,13 +925,15 @@ extern "C" int avl_fused_frame(const avl_grid* g, const void* pts, int n, int dt
     hipStream_t s = avl::as_stream(stream);
     const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
     const bool scan = use_scan(g, n);
-    const int mode = !scan ? 0 : (byte_mask_ok(g, bonus_classes) ? 2 : 1);
-    if (mode == 0) AVL_HIP_CHECK(hipMemsetAsync(g->counter, 0, 16, s));      // only the touched-list path counts
-#define AVL_FV(SRC, MODE) hipLaunchKernelGGL((k_fused_vote<SRC, MODE>), grid, block, 0, s, pv, pp, gp, src, src_w, src_h, lut, g->cell_mask, g->touched, g->counter)
-    if (src_kind == AVL_SRC_RGB) { if (mode == 2) AVL_FV(AVL_SRC_RGB, 2); else if (mode == 1) AVL_FV(AVL_SRC_RGB, 1); else AVL_FV(AVL_SRC_RGB, 0); }
-    else { if (mode == 2) AVL_FV(AVL_SRC_CLASSMAP, 2); else if (mode == 1) AVL_FV(AVL_SRC_CLASSMAP, 1); else AVL_FV(AVL_SRC_CLASSMAP, 0); }
+    const int mode = use_lists(g, n, bonus_classes) ? 3 : !scan ? 0 : (byte_mask_ok(g, bonus_classes) ? 2 : 1);
+    if (mode == 0) AVL_HIP_CHECK(hipMemsetAsync(g->counter, 0, 16, s));      // only the single touched-list path counts there
+    const int list_cap = list_geom(n).cap;
+#define AVL_FV(SRC, MODE) hipLaunchKernelGGL((k_fused_vote<SRC, MODE>), grid, block, 0, s, pv, pp, gp, src, src_w, src_h, lut, g->cell_mask, g->touched, g->counter, list_cap)
+    if (src_kind == AVL_SRC_RGB) { if (mode == 3) AVL_FV(AVL_SRC_RGB, 3); else if (mode == 2) AVL_FV(AVL_SRC_RGB, 2); else if (mode == 1) AVL_FV(AVL_SRC_RGB, 1); else AVL_FV(AVL_SRC_RGB, 0); }
+    else { if (mode == 3) AVL_FV(AVL_SRC_CLASSMAP, 3); else if (mode == 2) AVL_FV(AVL_SRC_CLASSMAP, 2); else if (mode == 1) AVL_FV(AVL_SRC_CLASSMAP, 1); else AVL_FV(AVL_SRC_CLASSMAP, 0); }
 #undef AVL_FV
     AVL_LAUNCH_CHECK();
+    if (mode == 3) return launch_apply_lists(g, cm_host, bonus_classes, n, s);
     if (mode == 2) return launch_sweep_bytes(g, cm_host, bonus_classes, s);
     return mode == 1 ? launch_apply_scan(g, cm_host, s) : launch_apply(g, cm_host, nullptr, 0, s);
 }

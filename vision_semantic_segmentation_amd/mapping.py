@@ -73,13 +73,13 @@ class DeviceGrid(object):
         self.torch_dtype = torch.float64 if dtype == "f64" else torch.float32
         self.map = torch.zeros((self.Hm, self.Wm, self.C), dtype=self.torch_dtype, device=device)
         self.cell_mask = torch.zeros(self.Hm * self.Wm, dtype=torch.int32, device=device)
-        self.counter = torch.zeros(4, dtype=torch.int32, device=device)
+        self.counter = torch.zeros(_lib.AVL_COUNTER_INTS, dtype=torch.int32, device=device)
         self.touched = None
         self.touched_cap = 0
         self.ensure_capacity(1 << 17)
 
     def ensure_capacity(self, n):
-        need = min(int(n), self.Hm * self.Wm)
+        need = min(int(n), self.Hm * self.Wm) + 64 * 256      # + the rounding slack of the partitioned lists (mapping.hip, kLists)
         if need > self.touched_cap:
             self.touched_cap = max(need, 2 * self.touched_cap)
             self.touched = torch.empty(self.touched_cap, dtype=torch.int32, device=self.device)
@@ -97,6 +97,7 @@ class DeviceGrid(object):
         g.touched = self.touched.data_ptr()
         g.touched_cap = self.touched_cap
         g.counter = self.counter.data_ptr()
+        g.counter_len = int(self.counter.numel())
         return g
 
 
