@@ -57,6 +57,8 @@ def self_launch(args):
            str(args.warmup), "--precision", args.precision, "--mixed-opts", args.mixed_opts]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
+    if args.no_other_precisions:
+        cmd.append("--no-other-precisions")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
 
@@ -68,6 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--precision", default="mixed", choices=["mixed", "bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle runs (no parity block, no cpu_baseline)")
+    ap.add_argument("--no-other-precisions", action="store_true", help="skip the bf16 / f16 context runs (other_precisions block)")
     ap.add_argument("--mixed-opts", default="", help="comma list of key=0|1 overrides for the mixed mode (conv2_split, mx, trunk_fp4, conv1_split)")
     args = ap.parse_args()
 
@@ -151,10 +154,12 @@ def main():
         roofline = gemm_roofline(net, args.precision)
         fps_h2d = fps_with_uploads(net, sm, cam, image_host, points_host, dev, min(args.steps, 60), max(3, min(args.warmup, 10)))
         mapping = mapping_block(dev, rng)
-        parity, cpu_baseline = None, None
+        parity, cpu_baseline, other = None, None, None
         if not args.no_cpu_baseline:
-            parity, cpu_baseline = parity_and_cpu_baseline(net, state, cfg, sm.confusion_matrix, cam, image, image_host, points, dev,
-                                                           want_baseline=(world == 1))
+            parity, cpu_baseline, logits_ref = parity_and_cpu_baseline(net, state, cfg, sm.confusion_matrix, cam, image, image_host, points,
+                                                                       dev, want_baseline=(world == 1))
+            if world == 1 and not args.no_other_precisions:
+                other = other_precisions(args.precision, state, cfg, sm.confusion_matrix, cam, image, points, dev, logits_ref)
         result = {
             "metric": "fused frames/sec/GPU (1920x1080 + 120k pts) + max|dlog-odds| vs ref",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -167,6 +172,7 @@ def main():
                        "precision": args.precision, "frame": [H, W], "points": NPTS, "grid": [sm.map_height, sm.map_width, sm.map_depth],
                        "parallelism": "frame-parallel x%d, 1 grid all-reduce" % world},
             "roofline": roofline, "parity": parity, "mapping": mapping, "cpu_baseline": cpu_baseline,
+            "other_precisions": other,
         }
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -178,14 +184,20 @@ def main():
 def gemm_roofline(net, precision):
     """Roofline of the dominant kernel (the 1x1-conv GEMM) from per-launch HIP events on the launch stream.  `achieved`
     counts ALGORITHMIC flops (2 M N K per launch); in the mixed mode the matrix cores execute 2 or 3 f16 passes per
-    product, reported next to it as `executed_tflops`."""
+    product (MX GEMMs: one f16 pass + one or two FP4 passes of a quarter of the MFMAs each), reported next to it as
+    `executed_tflops` in f16-pass equivalents."""
     prof = net.profile()
     for _ in range(2):
         for a, b in zip(prof, net.profile()):
             a["ms"] = min(a["ms"], b["ms"])
     gemm = [(p, op) for p, op in zip(prof, net.ops) if p["kind"] == "gemm"]
     g_ms, g_fl = sum(p["ms"] for p, _ in gemm), sum(p["flops"] for p, _ in gemm)
-    g_exec = sum(p["flops"] * ((3 if op.in_lo else 2) if op.w_split else 1) for p, op in gemm)
+    def passes(op):          # matrix-pipe work in f16-pass equivalents: an FP4 correction pass issues a quarter of the MFMAs of an f16 one
+        if op.w_split == 2:
+            return 1.0 + 0.25 * (2 if (op.in_lo or (op.mx_flags & 1)) else 1)
+        return (3 if op.in_lo else 2) if op.w_split else 1
+
+    g_exec = sum(p["flops"] * passes(op) for p, op in gemm)
     seg_ms, seg_fl = sum(p["ms"] for p in prof), sum(p["flops"] for p in prof)
     peak = PEAK_F32_TFLOPS if precision == "f32" else PEAK_MFMA16_TFLOPS
     achieved = g_fl / g_ms / 1e9
@@ -312,6 +324,44 @@ def mapping_block(dev, rng):
     return out
 
 
+def other_precisions(default_precision, state, cfg, cm, cam, image, points, dev, logits_ref, steps=30):
+    """The same workload in the other MODEL.PRECISION settings, for context next to the headline mode (never `value`):
+    fused frames/s over `steps` frames, logits error against the same oracle output, GEMM roofline of that mode."""
+    import torch
+    from vision_semantic_segmentation_amd import SemanticMapping
+    from vision_semantic_segmentation_amd.network import SegNet
+    from vision_semantic_segmentation_amd.utils.logger import MyLogger
+    out = {}
+    for prec in ("bf16", "f16"):
+        if prec == default_precision:
+            continue
+        net2 = SegNet(state, H, W, precision=prec, device=dev)
+        net2.image.copy_(image)
+        net2.capture_graph()
+        sm2 = SemanticMapping(cfg, device=dev, logger=MyLogger("bench", quiet=True))
+        sm2.confusion_matrix = cm
+
+        def step():
+            labels = net2.forward()
+            sm2.frame_device(points, "velodyne", labels, None, cam, src_kind="classmap", image_size=(H, W))
+
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        fps = steps / (time.perf_counter() - t0)
+        logits = net2.logits.permute(2, 0, 1).float().cpu()
+        rel = float((logits - logits_ref).abs().max() / logits_ref.abs().max())
+        roof = gemm_roofline(net2, prec)
+        out[prec] = {"fps": round(fps, 2), "logits_max_rel_err": rel, "gemm_tflops": roof["achieved"], "gemm_frac_of_peak": roof["frac"]}
+        del net2, sm2
+        torch.cuda.empty_cache()
+    return out
+
+
 def parity_and_cpu_baseline(net, state, cfg, cm, cam, image, image_host, points, dev, want_baseline):
     """Parity of this very workload.  The oracle network (torch CPU fp32) runs ONCE on the full 1080 x 1920 frame: its
     logits check the GPU's, its own arg-max feeds the oracle mapping, and its wall time is the network half of the CPU
@@ -363,7 +413,7 @@ def parity_and_cpu_baseline(net, state, cfg, cm, cam, image, image_host, points,
         baseline = {"value": round(1.0 / (t_net + t_map), 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                     "sample": "one full 1080x1920 frame + 120k points: oracle network (torch CPU fp32, %d threads) %.2f s, oracle mapping "
                               "(NumPy, 1 thread, min of 2) %.1f ms" % (torch.get_num_threads(), t_net, 1e3 * t_map)}
-    return parity, baseline
+    return parity, baseline, logits_ref
 
 
 if __name__ == "__main__":
