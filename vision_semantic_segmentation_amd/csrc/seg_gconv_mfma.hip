@@ -224,9 +224,15 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
             } else {
                 // ONE conversion to the 16-bit type: the packed vector is what gets stored AND what hi is read back from
                 typedef typename Half16<HT>::v8 h8;
-                h8 hv;
+                typedef HT h2 __attribute__((ext_vector_type(2)));
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                u4 hpk;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) hv[r] = (HT)v[r];
+                for (int r = 0; r < 4; ++r) {          // pairs: one v_cvt_pk_f16_f32 each (element-wise conversion cost a cvt + a perm per pair)
+                    const h2 t = {(HT)v[2 * r], (HT)v[2 * r + 1]};
+                    hpk[r] = __builtin_bit_cast(unsigned, t);
+                }
+                const h8 hv = __builtin_bit_cast(h8, hpk);
                 if (live) *reinterpret_cast<h8*>(p.out + (pix * o_ld + (unsigned)cbase)) = hv;
                 float lo[8];
 #pragma unroll
