@@ -33,11 +33,21 @@ int launch(const avl_seg_op& op, hipStream_t s) {
 }
 
 // algorithmic work of one op: flops (2 per MAC) and bytes (each tensor touched once)
+// Bytes per element of an activation as the op touches it: the 16-bit (or fp32) plane, a second plane when it is split, and
+// the FP4 copies of an MX bundle (half a byte per element and plane + one scale byte per 32 elements).
+static double act_bytes(double es, bool lo_plane, bool mx, bool mx_lo) {
+    double b = es + (lo_plane ? es : 0.0);
+    if (mx) b += (mx_lo ? 2.0 : 1.0) * (0.5 + 1.0 / 32.0);
+    return b;
+}
+
 void work(const avl_seg_op& op, double& flops, double& bytes) {
     const double es = elem_size(op.dtype);
     const double in_pix = (double)op.in_h * op.in_w, out_pix = (double)op.out_h * op.out_w;
+    const double e_in = act_bytes(es, op.in_lo != nullptr, op.in_mx != nullptr, (op.mx_flags & AVL_MX_IN_LO) || op.in_lo);
+    const double e_out = act_bytes(es, op.out_lo != nullptr, op.out_mx != nullptr, (op.mx_flags & AVL_MX_OUT_LO) || op.out_lo);
     flops = 0;
-    bytes = in_pix * op.in_c * es + out_pix * op.out_c * es;
+    bytes = in_pix * op.in_c * e_in + out_pix * op.out_c * e_out;
     switch (op.kind) {
         case AVL_OP_STEM:
             flops = 2.0 * out_pix * 64 * 147;
@@ -45,12 +55,17 @@ void work(const avl_seg_op& op, double& flops, double& bytes) {
             break;
         case AVL_OP_GEMM:
             flops = 2.0 * out_pix * op.out_c * (op.in_c + (op.in3 ? op.in3_c : 0));
-            bytes += (double)op.out_c * (op.in_c + (op.in3 ? op.in3_c : 0)) * es + (op.in2 ? out_pix * op.out_c * es : 0.0) +
-                     (op.in3 ? in_pix * op.in3_c * es : 0.0);
+            {
+                const double k_all = op.in_c + (op.in3 ? op.in3_c : 0);
+                const double e_w = op.w_split == 2 ? es + 2.0 * (0.5 + 1.0 / 32.0) : es * (op.w_split ? 2.0 : 1.0);      // hi + lo, or hi + two FP4 copies
+                const double e_res = act_bytes(es, op.in2_lo != nullptr, (op.mx_flags & AVL_MX_RES_LO) != 0, false);
+                bytes += (double)op.out_c * k_all * e_w + (op.in2 ? out_pix * op.out_c * e_res : 0.0) + (op.in3 ? in_pix * op.in3_c * e_in : 0.0);
+            }
             if (op.out_f32) bytes += out_pix * op.out_c * (4 - es);
             break;
         case AVL_OP_GCONV:
             flops = 2.0 * out_pix * op.out_c * (op.in_c / op.groups) * 9;
+            bytes += (double)op.out_c * (op.in_c / op.groups) * 9 * es * (op.w_split ? 2.0 : 1.0);
             break;
         case AVL_OP_DWCONV:
             flops = 2.0 * out_pix * op.out_c * 9;
