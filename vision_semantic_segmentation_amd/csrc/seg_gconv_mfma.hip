@@ -40,10 +40,28 @@ struct GconvArgs {
     int nsp, nslots;     // pixel tiles (all residue classes), and how many of them are in flight (workgroups per channel chunk)
     int tile_bytes;      // one LDS tile buffer
     int tw_magic;        // ceil(65536 / input tile width): pix / in_tw == (pix * tw_magic) >> 16 for every pixel of a tile
+    // WS = 2 (MX variant, see below): FP4 copies of the weights and of the input
+    const char* w4;      // FP4 fragments [window][nj 2][pair 2][g 3][lane 64][16 B]; pair 0 = Q4(W lo), 1 = Q4(W hi)
+    const char* w4s;     // their scales [window][lane 64][12 B] (byte index nj * 6 + pair * 3 + g)
+    const char* xq[2];   // FP4 planes of the input [rows][C/2]: hi part, lo part (NULL: no lo correction)
+    const char* xs[2];   // scales [C/256][rows][8]
+    long long x_srows;
 };
 
 // WS = 1 ("mixed" precision): the weights come as f16 pairs hi + lo ([window][nj 2][tap 18 = 9 hi, 9 lo][16][32]); both
 // parts multiply the same input fragment into the same accumulator (fp32), i.e. the weights keep ~22 significant bits.
+//
+// WS = 2 (MX variant, MODEL.MIXED_GCONV_MX: blocks whose conv1 ran as an MX GEMM): the input is an f16 plane plus its MX
+// bundle (FP4 copies of its hi part and of its lo part, include/avl_hip.h), the weights are f16 hi fragments plus FP4 copies:
+//     out = Wh . xh                       f16 MFMA, one per tap and n-tile (K = the window's 32 channels)
+//         + Q4(Wl) . Q4(xh) + Q4(Wh) . Q4(xl)     v_mfma_scale_f32_16x16x128_f8f6f4: K = 128 = FOUR TAPS x 32 channels,
+//                                                 so three scaled MFMAs cover the nine taps (the last one is 3/4 zeros)
+// An MX block is the 32 channels of one window at one pixel (activations) / of one output row and tap (weights): exactly
+// the blocks the producers' epilogues quantise.  Lane (pixel fr, K block kq) of a scaled MFMA reads the 16 bytes of the
+// pixel that tap 4 g + kq falls on, and that pixel's scale byte.  Both corrections come to 12 scaled MFMAs per sub-tile next
+// to the 18 f16 ones (the f16-only form of split weights needs 36 and cannot correct for xl at all).  The LDS tile buffer
+// then also holds the FP4 tiles (plane 2 x window 2, 16 B per pixel, 64 pixels per DMA instruction) and one scale dword per
+// pixel and plane.
 template <typename HT, int WS, int NJ>      // NJ = tile height / 2: sub-tiles per wave and tile
 __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
     typedef typename Half16<HT>::v8 v8;
@@ -72,6 +90,11 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
     const int npix = in_th * in_tw;
     const int ngroups = (npix + 7) >> 3;
     const unsigned lds0 = lds_addr(lds);
+    // MX: [f16 tile: ngroups KB][FP4 tiles (plane 2 x window 2): n64 KB each][scale dwords (plane 2): n64 x 256 B each]
+    const int n64 = (npix + 63) >> 6;
+    const int QBASE = ngroups * 1024, QT = n64 * 1024, SBASE = QBASE + 4 * QT, ST = n64 * 256;
+    const bool has_lo = WS == 2 && p.xq[1] != nullptr;
+    const int nplanes = has_lo ? 2 : 1;
 
     // ---- stage one input tile (+halo) by LDS-DMA: one wave-instruction = 8 pixels x 128 B, all of a wave's transfers in
     // flight at once.  The DMA writes LDS lane-linearly, so the chunk swizzle goes on the SOURCE address.  Pixels outside
@@ -97,6 +120,30 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
             glds16_saddr(p.in + c0, voff, lds0 + buf * p.tile_bytes + gi * 1024);
             oob |= (inside ? 0u : 1u) << it;
         }
+        if constexpr (WS == 2) {
+            // FP4 tiles: item = (plane, window, 64-pixel group); lane = pixel; out-of-image pixels are zeroed later (bits 16+)
+            it = 16;
+            for (int item = wave; item < nplanes * 2 * n64; item += 8, ++it) {
+                const int gq = item % n64, pw = item / n64, w = pw & 1, pl = pw >> 1;
+                const int pix = gq * 64 + lane;
+                const int ly = (pix * p.tw_magic) >> 16, lx = pix - ly * in_tw;
+                const int iy = iy0 + ly * step, ix = ix0 + lx * step;
+                const bool inside = pix < npix && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+                glds16_saddr(p.xq[pl] + c0 / 2 + w * 16, (unsigned)(cy * p.W + cx) * (unsigned)(p.C / 2),
+                             lds0 + buf * p.tile_bytes + QBASE + (pl * 2 + w) * QT + gq * 1024);
+                oob |= (inside ? 0u : 1u) << it;
+            }
+            // one scale dword per pixel and plane (the four windows of this 128-channel half); a clamped pixel's scales are valid
+            for (int item = wave; item < nplanes * n64; item += 8) {
+                const int gq = item % n64, pl = item / n64;
+                const int pix = gq * 64 + lane;
+                const int ly = (pix * p.tw_magic) >> 16, lx = pix - ly * in_tw;
+                const int cy = min(max(iy0 + ly * step, 0), p.H - 1), cx = min(max(ix0 + lx * step, 0), p.W - 1);
+                glds4_saddr(p.xs[pl] + ((long long)(c0 >> 8) * p.x_srows) * 8 + ((c0 >> 5) & 4), (unsigned)(cy * p.W + cx) * 8u,
+                            lds0 + buf * p.tile_bytes + SBASE + pl * ST + gq * 256);
+            }
+        }
         return oob;
     };
     int sp = slot, buf = 0;
@@ -106,7 +153,7 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
     const int win = wave & 1;                  // window inside the 64-channel chunk
     const int part = wave >> 1;                // which quarter of each tile's sub-tiles
     const int fr = lane & 15, kq = lane >> 4;
-    constexpr int NT = WS ? 18 : 9;
+    constexpr int NT = WS == 1 ? 18 : 9;
     v8 wf[2][NT];
     {
         const HT* wp = p.w + (long long)(cchunk * 2 + win) * (2 * NT * 16 * 32);
@@ -116,6 +163,21 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
             for (int t = 0; t < NT; ++t)
                 wf[nj][t] = *reinterpret_cast<const v8*>(wp + ((nj * NT + t) * 16 + fr) * 32 + kq * 8);
     }
+    int4 w4[WS == 2 ? 2 : 1][2][3];
+    unsigned w4sc[3] = {0u, 0u, 0u};
+    if constexpr (WS == 2) {
+        const long long widx = cchunk * 2 + win;
+        const char* w4p = p.w4 + widx * (2 * 2 * 3 * 64 * 16) + lane * 16;
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) w4[nj][pr][g] = *reinterpret_cast<const int4*>(w4p + ((nj * 2 + pr) * 3 + g) * (64 * 16));
+        const unsigned* sp = reinterpret_cast<const unsigned*>(p.w4s + widx * (64 * 12) + lane * 12);
+        w4sc[0] = sp[0]; w4sc[1] = sp[1]; w4sc[2] = sp[2];
+    }
+    const int ssel = 8 * (((c0 >> 5) & 3) + win);           // MX: bit offset of this window's scale byte in a pixel's scale dword
     // lane's 8 output channels: window base + q*8 + nj*4 + r
     const int cbase = c0 + win * 32 + kq * 8;
     const int chunk_in = win * 4 + kq;         // this lane's 16-byte chunk of the pixel row (8 input channels)
@@ -134,6 +196,14 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
             int it = 0;
             for (int gi = wave; gi < ngroups; gi += 8, ++it)
                 if ((mask >> it) & 1u) *reinterpret_cast<uint4*>(lds + b * p.tile_bytes + gi * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (WS == 2) {
+                it = 16;
+                for (int item = wave; item < nplanes * 2 * n64; item += 8, ++it)
+                    if ((mask >> it) & 1u) {
+                        const int gq = item % n64, pw = item / n64;
+                        *reinterpret_cast<uint4*>(lds + b * p.tile_bytes + QBASE + pw * QT + gq * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+                    }
+            }
         }
     };
     zero_oob(oob, 0);
@@ -141,7 +211,7 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
 
     // LDS byte offsets of the nine taps of each of this lane's sub-tiles: tile-invariant.  With one or two sub-tiles per wave
     // they are kept in registers (9 x NJ); with four there is no room (256 VGPRs) and they are recomputed per tile.
-    constexpr bool HOIST = NJ <= 2;
+    constexpr bool HOIST = NJ <= 2 && WS != 2;      // (the MX variant has no registers to spare either)
     int toff[HOIST ? NJ : 1][9];
     if constexpr (HOIST) {
 #pragma unroll
@@ -187,13 +257,52 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
             }
             // the accumulators start from the bias (the epilogue is VALU-issue bound next to the MFMAs: every op saved there counts)
             f32x4 acc0 = bias0, acc1 = bias1;
+            if constexpr (WS == 2) {
+                // FP4 operands: this lane's K block of scaled MFMA g is tap 4 g + kq (taps past the ninth carry zero weights: any pixel)
+                typedef int v8i __attribute__((ext_vector_type(8)));
+                const int st2 = part + 4 * j;
+                const int sy2 = st2 >> 1, sx2 = (st2 & 1) * 16 + fr;
+                int4 bq[2][3];
+                int bs[2][3];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                acc0 = Half16<HT>::mfma(wf[0][t], a[t], acc0);
-                acc1 = Half16<HT>::mfma(wf[1][t], a[t], acc1);
-                if constexpr (WS != 0) {
-                    acc0 = Half16<HT>::mfma(wf[0][9 + t], a[t], acc0);
-                    acc1 = Half16<HT>::mfma(wf[1][9 + t], a[t], acc1);
+                for (int g = 0; g < 3; ++g) {
+                    const int t = min(4 * g + kq, 8);
+                    const int pix = (sy2 * s + (t / 3) * d) * in_tw + sx2 * s + (t % 3) * d;
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        if (pl == 1 && !has_lo) { bq[pl][g] = make_int4(0, 0, 0, 0); bs[pl][g] = 127; continue; }
+                        bq[pl][g] = *reinterpret_cast<const int4*>(tile + QBASE + (pl * 2 + win) * QT + pix * 16);
+                        bs[pl][g] = (int)((*reinterpret_cast<const unsigned*>(tile + SBASE + pl * ST + pix * 4) >> ssel) & 0xffu);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    acc0 = Half16<HT>::mfma(wf[0][t], a[t], acc0);
+                    acc1 = Half16<HT>::mfma(wf[1][t], a[t], acc1);
+                }
+#define AVL_GMX(NJ_, PR, G, ACC)                                                                                                \
+    {                                                                                                                          \
+        const v8i wa = {w4[NJ_][PR][G].x, w4[NJ_][PR][G].y, w4[NJ_][PR][G].z, w4[NJ_][PR][G].w, 0, 0, 0, 0};                    \
+        const v8i xa = {bq[PR][G].x, bq[PR][G].y, bq[PR][G].z, bq[PR][G].w, 0, 0, 0, 0};                                        \
+        ACC = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, ACC, 4, 4, ((NJ_) * 6 + (PR) * 3 + (G)) & 3,              \
+                                                               (int)w4sc[((NJ_) * 6 + (PR) * 3 + (G)) >> 2], 0, bs[PR][G]);     \
+    }
+                AVL_GMX(0, 0, 0, acc0) AVL_GMX(0, 0, 1, acc0) AVL_GMX(0, 0, 2, acc0)
+                AVL_GMX(1, 0, 0, acc1) AVL_GMX(1, 0, 1, acc1) AVL_GMX(1, 0, 2, acc1)
+                if (has_lo) {
+                    AVL_GMX(0, 1, 0, acc0) AVL_GMX(0, 1, 1, acc0) AVL_GMX(0, 1, 2, acc0)
+                    AVL_GMX(1, 1, 0, acc1) AVL_GMX(1, 1, 1, acc1) AVL_GMX(1, 1, 2, acc1)
+                }
+#undef AVL_GMX
+            } else {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    acc0 = Half16<HT>::mfma(wf[0][t], a[t], acc0);
+                    acc1 = Half16<HT>::mfma(wf[1][t], a[t], acc1);
+                    if constexpr (WS == 1) {
+                        acc0 = Half16<HT>::mfma(wf[0][9 + t], a[t], acc0);
+                        acc1 = Half16<HT>::mfma(wf[1][9 + t], a[t], acc1);
+                    }
                 }
             }
             acc[j][0] = acc0; acc[j][1] = acc1;
@@ -287,250 +396,6 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// MX variant ("mixed" precision, blocks whose conv1 ran as an MX GEMM): the input is an f16 plane plus its MX bundle
-// (FP4 copies of its hi part and of its lo part, include/avl_hip.h), the weights are f16 hi fragments plus FP4 copies:
-//     out = Wh . xh                       f16 MFMA, one per tap and n-tile (K = the window's 32 channels)
-//         + Q4(Wl) . Q4(xh) + Q4(Wh) . Q4(xl)     v_mfma_scale_f32_16x16x128_f8f6f4: K = 128 = FOUR TAPS x 32 channels,
-//                                                 so three scaled MFMAs cover the nine taps (the last one is 3/4 zeros)
-// An MX block is the 32 channels of one window at one pixel (activations) / of one output row and tap (weights): exactly
-// the blocks the producers' epilogues quantise.  Lane (pixel fr, K block kq) of a scaled MFMA reads the 16 bytes of the
-// pixel that tap 4 g + kq falls on, and that pixel's scale byte.  Both corrections come to 12 scaled MFMAs per sub-tile next to
-// the 18 f16 ones (the f16-only form of split weights needs 36 and cannot correct for xl at all).
-struct GconvMxArgs {
-    const f16* in;
-    const f16* w;            // hi fragments [window][nj 2][tap 9][i 16][ci 32]
-    const char* w4;          // FP4 fragments [window][nj 2][pair 2][g 3][lane 64][16 B]; pair 0 = Q4(W lo), 1 = Q4(W hi)
-    const char* w4s;         // their scales [window][lane 64][12 B] (byte index nj * 6 + pair * 3 + g)
-    const char* xq[2];       // FP4 planes of the input [rows][C/2]: hi part, lo part (NULL: no lo correction)
-    const char* xs[2];       // scales [C/256][rows][8]
-    long long x_srows;
-    const float* bias;
-    f16* out;
-    f16* out_lo;
-    char* oq[2];
-    char* os[2];
-    long long o_srows;
-    int H, W, in_ld, OH, OW, out_ld, C;
-    int stride, dil, th, tiles_x, tiles_y, cchunks, comb;
-};
-
-__global__ void __launch_bounds__(256) k_gconv_mx(GconvMxArgs p) {
-    typedef f16 HT;
-    typedef Half16<HT>::v8 v8;
-    typedef int v8i __attribute__((ext_vector_type(8)));
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = blockIdx.x;
-    {
-        // XCD-aware, bijective remap (workgroups b, b+8, ... share an XCD and its L2): each XCD takes a contiguous run of
-        // tiles, so neighbouring tiles share their halo in one L2
-        const int nwg = gridDim.x, xcd = bid & 7, local = bid >> 3, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-    }
-    const int cchunk = bid % p.cchunks;
-    bid /= p.cchunks;
-    const int tx = bid % p.tiles_x;
-    bid /= p.tiles_x;
-    const int ty = bid % p.tiles_y, cmb = bid / p.tiles_y;
-    const int s = p.stride;
-    const int d = p.comb ? 1 : p.dil;
-    const int step = p.comb ? p.dil : 1;
-    const int ry = p.comb ? cmb / p.dil : 0, rx = p.comb ? cmb % p.dil : 0;
-    const int oy0 = ty * p.th, ox0 = tx * TW;
-    const int in_th = (p.th - 1) * s + 2 * d + 1, in_tw = (TW - 1) * s + 2 * d + 1;
-    const int iy0 = ry + (oy0 * s - d) * step, ix0 = rx + (ox0 * s - d) * step;
-    const int c0 = cchunk * CC;
-    const int npix = in_th * in_tw;
-    const int ngroups = (npix + 7) >> 3;
-    const int n64 = (npix + 63) >> 6;                      // 64-pixel DMA groups of the FP4 tiles
-    // LDS: [f16 tile: ngroups x 1 KB][FP4 tiles (plane 2 x window 2): n64 x 1 KB each][scale dwords (plane 2): n64 x 256 B each]
-    const int QBASE = ngroups * 1024, QT = n64 * 1024, SBASE = QBASE + 4 * QT, ST = n64 * 256;
-    const bool has_lo = p.xq[1] != nullptr;
-
-    auto pixel_of = [&](int pix, bool& inside) {           // tile pixel -> clamped global pixel index
-        const int ly = pix / in_tw, lx = pix - ly * in_tw;
-        const int iy = iy0 + ly * step, ix = ix0 + lx * step;
-        inside = pix < npix && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-        return (long long)cy * p.W + cx;
-    };
-    // ---- stage: f16 tile (8 pixels x 128 B per wave-instruction, chunk swizzle on the source), FP4 tiles and scale dwords
-    // (64 pixels per wave-instruction, lane-linear).  Pixels outside the image come from a clamped address and are zeroed.
-    unsigned oob = 0, oobq = 0;
-    {
-        const int prow = lane >> 3, cphys = lane & 7;
-        int it = 0;
-        for (int gi = wave; gi < ngroups; gi += 4, ++it) {
-            const int pix = gi * 8 + prow;
-            bool inside;
-            const long long gp = pixel_of(pix, inside);
-            const HT* src = p.in + gp * p.in_ld + c0 + ((cphys ^ (pix & 7)) << 3);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + gi * 1024), 16, 0, 0);
-            oob |= (inside ? 0u : 1u) << it;
-        }
-        const int nplanes = has_lo ? 2 : 1;
-        it = 0;
-        for (int item = wave; item < nplanes * 2 * n64; item += 4, ++it) {       // item = (plane, window, group)
-            const int gq = item % n64, pw = item / n64, w = pw & 1, pl = pw >> 1;
-            bool inside;
-            const long long gp = pixel_of(gq * 64 + lane, inside);
-            const char* src = p.xq[pl] + gp * (p.C / 2) + c0 / 2 + w * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + QBASE + (pl * 2 + w) * QT + gq * 1024), 16, 0, 0);
-            oobq |= (inside ? 0u : 1u) << it;
-        }
-        for (int item = wave; item < nplanes * n64; item += 4) {                  // item = (plane, group): one scale dword per pixel
-            const int gq = item % n64, pl = item / n64;
-            bool inside;
-            const long long gp = pixel_of(gq * 64 + lane, inside);
-            const char* src = p.xs[pl] + ((long long)(c0 >> 8) * p.x_srows + gp) * 8 + ((c0 >> 5) & 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + SBASE + pl * ST + gq * 256), 4, 0, 0);
-        }
-        if (oob | oobq) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            it = 0;
-            for (int gi = wave; gi < ngroups; gi += 4, ++it)
-                if ((oob >> it) & 1u) *reinterpret_cast<uint4*>(lds + gi * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
-            it = 0;
-            for (int item = wave; item < nplanes * 2 * n64; item += 4, ++it)
-                if ((oobq >> it) & 1u) {
-                    const int gq = item % n64, pw = item / n64;
-                    *reinterpret_cast<uint4*>(lds + QBASE + pw * QT + gq * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
-                }
-        }
-    }
-
-    // ---- this wave's window, its weight fragments (registers for the whole tile)
-    const int win = wave & 1, half = wave >> 1;
-    const int fr = lane & 15, kq = lane >> 4;
-    v8 wf[2][9];
-    int4 w4[2][2][3];
-    unsigned w4sc[3];
-    {
-        const long long widx = cchunk * 2 + win;
-        const HT* wp = p.w + widx * (2 * 9 * 16 * 32);
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-                wf[nj][t] = *reinterpret_cast<const v8*>(wp + ((nj * 9 + t) * 16 + fr) * 32 + kq * 8);
-        const char* w4p = p.w4 + widx * (2 * 2 * 3 * 64 * 16) + lane * 16;
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-                for (int g = 0; g < 3; ++g) w4[nj][pr][g] = *reinterpret_cast<const int4*>(w4p + ((nj * 2 + pr) * 3 + g) * (64 * 16));
-        const unsigned* sp = reinterpret_cast<const unsigned*>(p.w4s + widx * (64 * 12) + lane * 12);
-        w4sc[0] = sp[0]; w4sc[1] = sp[1]; w4sc[2] = sp[2];
-    }
-    const int cbase = c0 + win * 32 + kq * 8;
-    float bias[8];
-    {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cbase);
-        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cbase + 4);
-        bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
-        bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const int nsub = p.th * (TW / 16);
-    const int chunk_in = win * 4 + kq;
-    const int ssel = 8 * (((c0 >> 5) & 3) + win);           // bit offset of this window's scale byte in a pixel's scale dword
-    for (int st = half; st < nsub; st += 2) {
-        const int sy = st >> 1, sx = (st & 1) * 16 + fr;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        v8 a[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int pix = (sy * s + (t / 3) * d) * in_tw + sx * s + (t % 3) * d;
-            a[t] = *reinterpret_cast<const v8*>(lds + pix * 128 + ((chunk_in ^ (pix & 7)) << 4));
-        }
-        // FP4 operands: this lane's K block of scaled MFMA g is tap 4 g + kq (taps past the ninth carry zero weights: any pixel)
-        int4 bq[2][3];
-        int bs[2][3];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            const int t = min(4 * g + kq, 8);
-            const int pix = (sy * s + (t / 3) * d) * in_tw + sx * s + (t % 3) * d;
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                if (pl == 1 && !has_lo) { bq[pl][g] = make_int4(0, 0, 0, 0); bs[pl][g] = 127; continue; }
-                bq[pl][g] = *reinterpret_cast<const int4*>(lds + QBASE + (pl * 2 + win) * QT + pix * 16);
-                bs[pl][g] = (int)((*reinterpret_cast<const unsigned*>(lds + SBASE + pl * ST + pix * 4) >> ssel) & 0xffu);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            acc0 = Half16<HT>::mfma(wf[0][t], a[t], acc0);
-            acc1 = Half16<HT>::mfma(wf[1][t], a[t], acc1);
-        }
-#define AVL_GMX(NJ, PR, G, ACC)                                                                                                \
-    {                                                                                                                          \
-        const v8i wa = {w4[NJ][PR][G].x, w4[NJ][PR][G].y, w4[NJ][PR][G].z, w4[NJ][PR][G].w, 0, 0, 0, 0};                        \
-        const v8i xa = {bq[PR][G].x, bq[PR][G].y, bq[PR][G].z, bq[PR][G].w, 0, 0, 0, 0};                                        \
-        ACC = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, ACC, 4, 4, ((NJ) * 6 + (PR) * 3 + (G)) & 3,               \
-                                                               (int)w4sc[((NJ) * 6 + (PR) * 3 + (G)) >> 2], 0, bs[PR][G]);      \
-    }
-        AVL_GMX(0, 0, 0, acc0) AVL_GMX(0, 0, 1, acc0) AVL_GMX(0, 0, 2, acc0)
-        AVL_GMX(1, 0, 0, acc1) AVL_GMX(1, 0, 1, acc1) AVL_GMX(1, 0, 2, acc1)
-        if (has_lo) {
-            AVL_GMX(0, 1, 0, acc0) AVL_GMX(0, 1, 1, acc0) AVL_GMX(0, 1, 2, acc0)
-            AVL_GMX(1, 1, 0, acc1) AVL_GMX(1, 1, 1, acc1) AVL_GMX(1, 1, 2, acc1)
-        }
-#undef AVL_GMX
-        const int oy = ry + (oy0 + sy) * step, ox = rx + (ox0 + sx) * step;
-        if (oy < p.OH && ox < p.OW) {
-            float v[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = fmaxf(acc0[r] + bias[r], 0.f);
-                v[4 + r] = fmaxf(acc1[r] + bias[4 + r], 0.f);
-            }
-            Vec8<HT>::store(p.out + ((long long)oy * p.OW + ox) * p.out_ld + cbase, v);
-            float lo[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float h = (float)(HT)v[r];
-                lo[r] = v[r] - h;
-                if (p.out_lo) lo[r] = (float)(HT)lo[r];
-                v[r] = h;
-            }
-            if (p.out_lo) Vec8<HT>::store(p.out_lo + ((long long)oy * p.OW + ox) * p.out_ld + cbase, lo);
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                if (p.oq[pl] == nullptr) continue;
-                const float* src = pl == 0 ? v : lo;
-                float amax = 0.f;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) amax = fmaxf(amax, fabsf(src[r]));
-                amax = fmaxf(amax, __shfl_xor(amax, 16));
-                amax = fmaxf(amax, __shfl_xor(amax, 32));
-                const unsigned e = __float_as_uint(amax) >> 23;
-                const unsigned sbyte = e >= 3u ? e - 2u : 1u;
-                const float scale = __uint_as_float(sbyte << 23);
-                unsigned pk = 0u;
-                pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[0], src[1], scale, 0);
-                pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[2], src[3], scale, 1);
-                pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[4], src[5], scale, 2);
-                pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[6], src[7], scale, 3);
-                const long long pix = (long long)oy * p.OW + ox;
-                const unsigned p1 = __shfl(pk, lane + 16), p2 = __shfl(pk, lane + 32), p3 = __shfl(pk, lane + 48);
-                if (kq == 0) {
-                    *reinterpret_cast<uint4*>(p.oq[pl] + pix * (p.C / 2) + cbase / 2) = make_uint4(pk, p1, p2, p3);
-                    p.os[pl][((long long)(cbase >> 8) * p.o_srows + pix) * 8 + ((cbase >> 5) & 7)] = (char)sbyte;
-                }
-            }
-        }
-    }
-}
-
 }  // namespace
 
 int gconv_mfma_lds_bytes(int stride, int dil, int& th) {
@@ -539,9 +404,10 @@ int gconv_mfma_lds_bytes(int stride, int dil, int& th) {
     return ((in_th * in_tw + 7) / 8) * 1024;      // whole 8-pixel DMA groups
 }
 
-static int gconv_tile_bytes(int stride, int dil, int th) {
+static int gconv_tile_bytes(int stride, int dil, int th, bool mx = false) {
     const int in_th = (th - 1) * stride + 2 * dil + 1, in_tw = (TW - 1) * stride + 2 * dil + 1;
-    return ((in_th * in_tw + 7) / 8) * 1024;
+    const int npix = in_th * in_tw, n64 = (npix + 63) / 64;
+    return ((npix + 7) / 8) * 1024 + (mx ? 4 * n64 * 1024 + 2 * n64 * 256 : 0);      // + FP4 tiles and scale dwords (k_gconv_mfma, WS = 2)
 }
 
 static int device_cus() {
@@ -560,6 +426,7 @@ static int device_cus() {
 // few tiles per workgroup lose less to the last, partly filled round and to the rows past the image with the lower tile
 // (measured at 1080p: layer4 88 -> 83 us, layer2 32 -> 30 us with 4 rows; layer1 ties and keeps 8).
 static int gconv_pick_th(const avl_seg_op& op, int comb, int cus, int* nsp_out, int* nslots_out) {
+    const bool mx = op.w_split == 2;
     const int d = comb ? 1 : op.dil;
     const int gh = comb ? (op.out_h + op.dil - 1) / op.dil : op.out_h, gw = comb ? (op.out_w + op.dil - 1) / op.dil : op.out_w;
     const int ncomb = comb ? op.dil * op.dil : 1, cchunks = op.in_c / CC;
@@ -567,7 +434,8 @@ static int gconv_pick_th(const avl_seg_op& op, int comb, int cus, int* nsp_out, 
     double best_cost = 0.;
     static const int env_th = getenv("AVL_GCONV_TH") ? atoi(getenv("AVL_GCONV_TH")) : 0;      // experiments
     for (int th = 8; th >= 2; th >>= 1) {
-        if (2 * gconv_tile_bytes(op.stride, d, th) > 160 * 1024) continue;
+        if (2 * gconv_tile_bytes(op.stride, d, th, mx) > 160 * 1024) continue;
+        if (mx && th == 8) continue;                 // the MX variant with four sub-tiles per wave spills
         const int nsp = ((gw + TW - 1) / TW) * ((gh + th - 1) / th) * ncomb;
         int nslots = cus / cchunks;
         if (nslots < 1) nslots = 1;
@@ -603,12 +471,24 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
     a.stride = op.stride; a.dil = op.dil;
     a.comb = (op.stride == 1 && op.dil > 1 && op.pad == op.dil) ? 1 : 0;
     a.th = gconv_pick_th(op, a.comb, device_cus(), &a.nsp, &a.nslots);
-    a.tile_bytes = gconv_tile_bytes(op.stride, a.comb ? 1 : op.dil, a.th);
+    AVL_REQUIRE(a.th > 0, "grouped conv: no tile height fits two LDS buffers");
+    a.tile_bytes = gconv_tile_bytes(op.stride, a.comb ? 1 : op.dil, a.th, WS == 2);
+    a.w4 = a.w4s = a.xq[0] = a.xq[1] = a.xs[0] = a.xs[1] = nullptr;
+    a.x_srows = op.in_rows;
+    if (WS == 2) {
+        const long long nwin = op.in_c / 32;
+        a.w4 = static_cast<const char*>(op.w_mx);
+        a.w4s = a.w4 + nwin * (2 * 2 * 3 * 64 * 16);
+        const char* b = static_cast<const char*>(op.in_mx);
+        const long long rows = op.in_rows, P = rows * (op.in_c / 2), S = (long long)(op.in_c / 256) * rows * 8;
+        a.xq[0] = b; a.xs[0] = b + P;
+        if (op.mx_flags & AVL_MX_IN_LO) { a.xq[1] = b + P + S; a.xs[1] = b + 2 * P + S; }
+    }
     {
         const int d = a.comb ? 1 : op.dil;
         const int in_th = (a.th - 1) * op.stride + 2 * d + 1, in_tw = (TW - 1) * op.stride + 2 * d + 1;
         a.tw_magic = (65536 + in_tw - 1) / in_tw;
-        for (int pix = 0; pix < ((in_th * in_tw + 7) / 8) * 8; ++pix)
+        for (int pix = 0; pix < ((in_th * in_tw + 63) / 64) * 64; ++pix)
             AVL_REQUIRE(((pix * a.tw_magic) >> 16) == pix / in_tw, "grouped conv: tile %d x %d too large for the reciprocal division", in_th, in_tw);
     }
     const int gh = a.comb ? (op.out_h + op.dil - 1) / op.dil : op.out_h, gw = a.comb ? (op.out_w + op.dil - 1) / op.dil : op.out_w;
@@ -628,55 +508,8 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
     return AVL_OK;
 }
 
-int gconv_mx_lds_bytes(int stride, int dil, int& th) {
-    const int base = gconv_mfma_lds_bytes(stride, dil, th);
-    const int in_th = (th - 1) * stride + 2 * dil + 1, in_tw = (TW - 1) * stride + 2 * dil + 1;
-    const int n64 = (in_th * in_tw + 63) / 64;
-    return base + 4 * n64 * 1024 + 2 * n64 * 256;
-}
-
-int launch_gconv_mx(const avl_seg_op& op, hipStream_t s) {
-    GconvMxArgs a;
-    memset(&a, 0, sizeof(a));
-    a.in = static_cast<const f16*>(op.in);
-    a.w = static_cast<const f16*>(op.weight);
-    const long long nwin = op.in_c / 32;
-    a.w4 = static_cast<const char*>(op.w_mx);
-    a.w4s = a.w4 + nwin * (2 * 2 * 3 * 64 * 16);
-    {
-        const char* b = static_cast<const char*>(op.in_mx);
-        const long long rows = op.in_rows, P = rows * (op.in_c / 2), S = (long long)(op.in_c / 256) * rows * 8;
-        a.xq[0] = b; a.xs[0] = b + P;
-        if (op.mx_flags & AVL_MX_IN_LO) { a.xq[1] = b + P + S; a.xs[1] = b + 2 * P + S; }
-        a.x_srows = rows;
-    }
-    a.bias = op.bias;
-    a.out = static_cast<f16*>(op.out);
-    a.out_lo = static_cast<f16*>(op.out_lo);
-    a.o_srows = op.out_rows;
-    if (op.out_mx) {
-        char* b = static_cast<char*>(op.out_mx);
-        const long long rows = op.out_rows, P = rows * (op.out_c / 2), S = (long long)(op.out_c / 256) * rows * 8;
-        a.oq[0] = b; a.os[0] = b + P;
-        if (op.out_lo || (op.mx_flags & AVL_MX_OUT_LO)) { a.oq[1] = b + P + S; a.os[1] = b + 2 * P + S; }
-    }
-    a.H = op.in_h; a.W = op.in_w; a.in_ld = op.in_ld; a.OH = op.out_h; a.OW = op.out_w; a.out_ld = op.out_ld; a.C = op.in_c;
-    a.stride = op.stride; a.dil = op.dil;
-    a.comb = (op.stride == 1 && op.dil > 1 && op.pad == op.dil) ? 1 : 0;
-    const int ldsb = gconv_mx_lds_bytes(op.stride, a.comb ? 1 : op.dil, a.th);
-    const int gh = a.comb ? (op.out_h + op.dil - 1) / op.dil : op.out_h, gw = a.comb ? (op.out_w + op.dil - 1) / op.dil : op.out_w;
-    a.tiles_x = (gw + TW - 1) / TW;
-    a.tiles_y = (gh + a.th - 1) / a.th;
-    a.cchunks = op.in_c / CC;
-    const int ncomb = a.comb ? op.dil * op.dil : 1;
-    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv_mx), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(k_gconv_mx, dim3(a.tiles_x * a.tiles_y * a.cchunks * ncomb), dim3(256), ldsb, s, a);
-    AVL_LAUNCH_CHECK();
-    return AVL_OK;
-}
-
 int launch_gconv_mfma(const avl_seg_op& op, hipStream_t s) {
-    if (op.w_split == 2) return launch_gconv_mx(op, s);
+    if (op.w_split == 2) return launch_gconv_typed<f16, 2>(op, s);
     if (op.w_split) return launch_gconv_typed<f16, 1>(op, s);
     return op.dtype == AVL_F16 ? launch_gconv_typed<f16, 0>(op, s) : launch_gconv_typed<bf16, 0>(op, s);
 }
@@ -689,8 +522,8 @@ int validate_gconv_mfma(const avl_seg_op& op) {
     if (op.w_split == 2) {
         AVL_REQUIRE(op.w_mx && op.in_mx && op.in_c % 256 == 0 && op.in_ld == op.in_c, "MX grouped conv: w_mx, in_mx, channels %% 256 == 0, dense input rows");
         AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.w_mx) | reinterpret_cast<uintptr_t>(op.in_mx)) % 16 == 0, "MX grouped conv: unaligned bundles");
-        int th2;
-        AVL_REQUIRE(gconv_mx_lds_bytes(op.stride, (op.stride == 1 && op.pad == op.dil) ? 1 : op.dil, th2) <= 160 * 1024, "MX grouped conv tile does not fit LDS");
+        AVL_REQUIRE(2 * gconv_tile_bytes(op.stride, (op.stride == 1 && op.pad == op.dil) ? 1 : op.dil, 2, true) <= 160 * 1024, "MX grouped conv: two tile buffers do not fit LDS");
+        AVL_REQUIRE((long long)op.in_rows * (op.in_c / 2) < (1LL << 31), "MX grouped conv: FP4 plane beyond 2 GB (32-bit DMA offsets)");
     }
     AVL_REQUIRE(!op.out_mx || (op.w_split >= 1 && op.out_c % 256 == 0 && op.out_ld == op.out_c), "grouped conv: out_mx needs w_split, channels %% 256 == 0 and a dense output");
     AVL_REQUIRE(!(op.mx_flags & AVL_MX_OUT_LO) || (op.out_mx && !op.out_lo), "grouped conv: AVL_MX_OUT_LO needs out_mx and no out_lo");

@@ -119,6 +119,20 @@ __device__ __forceinline__ void glds16_saddr(const void* sbase, unsigned voff, u
         : "memory");
 }
 
+// 4 bytes per lane (64 x 4 B = 256 B per wave-instruction)
+__device__ __forceinline__ void glds4_saddr(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+        : "memory");
+}
+
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
