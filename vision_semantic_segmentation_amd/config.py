@@ -98,7 +98,7 @@ def get_network_cfg_defaults():
     # "f16" | "bf16": one 16-bit rounding per tensor (fastest; 2e-3 / 2e-2); "f32": fp32-input MFMA (1e-6, slowest)
     C.MODEL.PRECISION = "mixed"
     C.MODEL.MIXED_GCONV_MX = False      # "mixed" only: FP4 corrections inside the grouped 3x3 too (7.8e-4 instead of 8.8e-4 at 1080p, 5 % slower)
-    C.MODEL.MIXED_TRUNK_FP4 = True      # "mixed" only: keep the lo part of the residual trunk / 3x3 outputs as FP4 only (False: f16 lo planes, ~2 % slower, -0..14 % error)
+    C.MODEL.MIXED_TRUNK_FP4 = True      # "mixed" only: keep the lo part of the residual trunk / 3x3 outputs as FP4 only (False: f16 lo planes, 12 % slower, -0..14 % error)
     C.MODEL.MIXED_CONV2_SPLIT = True    # "mixed" only: keep every bottleneck's 3x3 output as hi + lo (conv3 corrects for both parts)
     C.MODEL.SEED = 0               # seed of the random weights used when MODEL.WEIGHT == ""
     C.MODEL.HIP_GRAPH = True       # replay the ~90-kernel plan as one hipGraph launch per frame
