@@ -1,0 +1,121 @@
+"""Host-side weight / activation packers of network.py ("mixed" precision): f16 splits, OCP MX-FP4 block quantisation in the
+byte order the GPU's converters use, the grouped conv's dense windows.  CPU only: no library call."""
+import numpy as np
+import pytest
+import torch
+
+from vision_semantic_segmentation_amd import network as N
+
+FP4 = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+
+
+def test_split_f16_keeps_22_bits():
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(64, 96, generator=g, dtype=torch.float64) * torch.logspace(-1, 2, 96, dtype=torch.float64)
+    hi, lo = N.split_f16(w)
+    assert hi.dtype == lo.dtype == torch.float16
+    assert torch.equal(hi, w.to(torch.float16))                                   # hi is THE f16 rounding of w
+    big = w.abs() >= 2.0 ** -4                                                    # (below that lo reaches f16's subnormals: absolute 2^-25 then)
+    rel = ((hi.double() + lo.double()) - w).abs() / w.abs()
+    assert float(rel[big].max()) < 2.0 ** -20
+    assert float(((hi.double() + lo.double()) - w).abs().max()) <= 2.0 ** -25 * max(1.0, float(w.abs().max()) * 2.0 ** 5)
+    assert float((lo.double().abs() / w.abs())[big].max()) <= 2.0 ** -10          # lo sits below hi's last bit
+
+
+def test_pack_split_rows_order():
+    w = torch.arange(2 * 128, dtype=torch.float64).reshape(2, 128) / 7.0
+    hi, lo = N.split_f16(w)
+    for nsub in (2, 3):
+        p = N.pack_split_rows(w, nsub).reshape(2, 2, nsub, 64)                    # [row][K block][pass][64]
+        assert torch.equal(p[:, :, 0], hi.reshape(2, 2, 64)) and torch.equal(p[:, :, 1], lo.reshape(2, 2, 64))
+        if nsub == 3:
+            assert torch.equal(p[:, :, 2], hi.reshape(2, 2, 64))
+
+
+def test_fp4_blocks_scale_rule_and_nibble_order():
+    # a block whose values lie ON the FP4 grid times a power of two is reproduced exactly
+    vals = torch.tensor(np.tile(np.concatenate([FP4, -FP4]), 2), dtype=torch.float64) * 2.0 ** 5      # max 6 * 32 = 192
+    packed, sbyte = N.fp4_quant_blocks(vals.reshape(1, 32))
+    assert int(sbyte[0]) == 127 + 5                                               # amax 192 = 6 * 2^5: exponent 7, minus 2
+    codes = np.stack([packed[0].numpy() & 15, packed[0].numpy() >> 4], axis=1).reshape(-1)           # element 2i in the LOW nibble
+    expect = np.tile(np.concatenate([np.arange(8), np.arange(8) | 8]), 2)
+    expect[8] = 0 | 8                                                             # -0.0 keeps its sign bit? (b < 0 is False for -0.0)
+    expect[8] = 0
+    expect[24] = 0
+    assert np.array_equal(codes, expect)
+    # the block maximum lands in [4, 8) and saturates to 6
+    b = torch.tensor([[7.9] + [0.1] * 31], dtype=torch.float64)
+    packed, sbyte = N.fp4_quant_blocks(b)
+    assert int(sbyte[0]) == 127 and (int(packed[0, 0]) & 15) == 7                 # 7.9 / 2^0 -> clamps to 6.0 (code 7)
+    # all-zero block: smallest legal scale byte, all codes zero
+    packed, sbyte = N.fp4_quant_blocks(torch.zeros(1, 32, dtype=torch.float64))
+    assert int(sbyte[0]) == 1 and not packed.any()
+
+
+def test_fp4_round_half_to_even():
+    # scale 1 (amax 4): 0.25 is midway between 0 (code 0) and 0.5 (code 1) -> even code 0; 0.75 between 0.5 (1) and 1.0 (2) -> 2;
+    # 2.5 between 2 (4) and 3 (5) -> 4; 3.5 between 3 (5) and 4 (6) -> 6; 5.0 between 4 (6) and 6 (7) -> 6
+    b = torch.zeros(1, 32, dtype=torch.float64)
+    b[0, :6] = torch.tensor([4.0, 0.25, 0.75, 2.5, 3.5, 5.0], dtype=torch.float64)
+    packed, sbyte = N.fp4_quant_blocks(b)
+    assert int(sbyte[0]) == 127
+    p = packed[0].numpy()
+    codes = np.stack([p & 15, p >> 4], axis=1).reshape(-1)[:6]
+    assert codes.tolist() == [6, 0, 2, 4, 6, 6]
+
+
+def test_mx_quant_roundtrip_and_layout():
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(48, 512, generator=g, dtype=torch.float64) * torch.logspace(-2, 1, 48, dtype=torch.float64).unsqueeze(1)
+    q, s = N.mx_quant_fp4(w)
+    assert q.shape == (48, 256) and q.dtype == torch.uint8
+    assert s.shape == (2, 48, 8) and s.dtype == torch.uint8                      # [K / 256][rows][8]: a tile's scales are contiguous
+    d = N.mx_dequant_fp4(q, s)
+    blocks = w.reshape(48, 16, 32)
+    amax = blocks.abs().amax(dim=2, keepdim=True)
+    err = (d.reshape(48, 16, 32) - blocks).abs()
+    assert float((err / amax).max()) <= 0.25 + 1e-12                              # worst case: the maximum itself saturating from <8 to 6
+    assert float((err / amax).mean()) < 0.05
+    # quantising what was decoded is a fixed point
+    q2, s2 = N.mx_quant_fp4(d)
+    assert torch.equal(N.mx_dequant_fp4(q2, s2), d)
+    assert N.mx_bundle_bytes(48, 512) == 48 * 256 + 2 * 48 * 8
+
+
+def test_pack_mx_weights_bundle_layout():
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(256, 256, generator=g, dtype=torch.float64)
+    hi, bundle = N.pack_mx_weights(w)
+    half = N.mx_bundle_bytes(256, 256)
+    assert hi.dtype == torch.float16 and bundle.dtype == torch.uint8 and bundle.numel() == 2 * half
+    whi, wlo = N.split_f16(w)
+    ql, sl = N.mx_quant_fp4(wlo.double())
+    qh, sh = N.mx_quant_fp4(whi.double())
+    assert torch.equal(bundle[:256 * 128].reshape(256, 128), ql)                  # first half: Q4(W lo) then its scales
+    assert torch.equal(bundle[256 * 128:half].reshape(1, 256, 8), sl)
+    assert torch.equal(bundle[half:half + 256 * 128].reshape(256, 128), qh)       # second half: Q4(W hi)
+    assert torch.equal(bundle[half + 256 * 128:].reshape(1, 256, 8), sh)
+
+
+@pytest.mark.parametrize("groups", [32, 16, 8])
+def test_grouped_conv_windows_are_block_diagonal(groups):
+    g = torch.Generator().manual_seed(3)
+    C = 128
+    cg = C // groups
+    w = torch.randn(C, cg, 3, 3, generator=g, dtype=torch.float64)
+    dense = N.gconv_dense_windows(w, groups)                                      # [window][co 32][tap 9][ci 32]
+    assert dense.shape == (C // 32, 32, 9, 32)
+    for co in (0, 5, 37, 127):
+        win, col = co // 32, co % 32
+        gbase = (col // cg) * cg
+        row = dense[win, col]                                                     # [tap][ci]
+        assert torch.equal(row[:, gbase:gbase + cg], w[co].reshape(cg, 9).t())    # the group's own channels ...
+        mask = torch.ones(32, dtype=torch.bool)
+        mask[gbase:gbase + cg] = False
+        assert not row[:, mask].any()                                             # ... and zeros towards every other group
+    # the fragment order of the MFMA kernel: row i of n-tile nj is output channel (i >> 2) * 8 + nj * 4 + (i & 3) of the window
+    frag = N.pack_gconv_windows(w, groups).reshape(C // 32, 2, 9, 16, 32)          # (returned flat)
+    for nj in (0, 1):
+        for i in (0, 3, 6, 15):
+            co_local = (i >> 2) * 8 + nj * 4 + (i & 3)
+            assert torch.equal(frag[1, nj, :, i, :].double(), dense[1, co_local])

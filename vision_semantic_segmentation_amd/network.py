@@ -307,7 +307,7 @@ def fp4_quant_blocks(b):
     element 2i in the LOW nibble of byte i -- the convention of the GPU's v_cvt_scalef32_pk_fp4_f32 (tools/micro/fp4_cvt_probe.hip)."""
     b = b.to(torch.float64)
     amax = b.abs().amax(dim=-1)
-    e = torch.floor(torch.log2(amax.clamp_min(2.0 ** -120))).to(torch.int64) + 127           # biased exponent of amax
+    e = (torch.floor(torch.log2(amax.clamp_min(2.0 ** -200))).to(torch.int64) + 127).clamp_min(0)   # biased fp32 exponent of amax (0: zero / subnormal, as the GPU reads it)
     sbyte = torch.where(e >= 3, e - 2, torch.ones_like(e)).clamp(1, 254)
     scale = torch.exp2((sbyte - 127).to(torch.float64)).unsqueeze(-1)
     mag = (b.abs() / scale).clamp_max(6.0)
