@@ -4,12 +4,15 @@
 One step = one pass of the hot path over one frame, inputs already resident in HBM:
     segmentation forward (DeepLabV3+/ResNeXt-50 OS8)  ->  uint8 label map (stays in HBM)
     -> LiDAR projection + label gather + BEV vote + grid update (avl_fused_frame)
-Default precision is "mixed" (f16 MFMA with split hi+lo operands): the mode whose logits stay within north_star's
-1e-3 of the reference's fp32 forward; `--precision bf16|f16` time the single-rounding 16-bit modes (faster, 2e-3 .. 2e-2).
+Default precision is "mixed" (f16 MFMA on hi+lo split operands, the correction products as MX-FP4 passes on the block-scaled
+matrix cores, fp32 accumulate): the mode whose logits stay within north_star's 1e-3 of the reference's fp32 forward on every
+weights draw measured (the `parity` block reports the WORST of two weight seeds); `--precision bf16|f16` time the
+single-rounding 16-bit modes (faster, 2e-3 .. 2e-2).
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), one camera stream and one private grid per
 rank, no data-path collective per frame; the shared global grid is formed by ONE all-reduce (sum) of the private
-grids, inside the timed region ("weak" scaling: per-GPU work fixed).
+grids (float32 payload: 80 MB for the 2000 x 2000 x 5 grid), inside the timed region and also timed on its own
+with HIP events (`exchange_ms`, `exchange_bytes`) ("weak" scaling: per-GPU work fixed).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) starts its N ranks itself: a child
@@ -18,8 +21,10 @@ touches the GPU; its exit code is this process's.  Launched under torch.distribu
 
 Rank 0 prints ONE JSON line (contract in the task statement) with
   roofline      dominant kernel = the 1x1-conv MFMA GEMM, HIP-event time per launch on the launch stream
-  parity        this very workload against the oracle: logits / arg-max of the network at the benchmarked precision,
-                the grid with the oracle fed ITS OWN labels (end to end) and fed the GPU's labels (mapping only)
+  parity        this very workload against the oracle, for two weight seeds (the bench's own and one more): logits / arg-max of
+                the network at the benchmarked precision, the grid with the oracle fed ITS OWN labels (end to end: the headline
+                field `max_abs_dlogodds_vs_oracle`) and fed the GPU's labels (mapping only: `grid_same_labels_*`); `worst` = the
+                worse of the two seeds, field by field
   mapping       the projection / vote / grid-update kernels alone: config C (120k points, 0.2 m) and config E (1M
                 points, 0.05 m): GPU microseconds per frame, algorithmic bytes, GB/s and fraction of the 8 TB/s HBM peak
   fps_incl_h2d  the same loop with the frame and the cloud uploaded from pinned host memory every frame (copy stream,
@@ -131,22 +136,34 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    ex0, ex1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def exchange():
+        """the one exchange step: private grids -> shared grid, ONE RCCL all-reduce of a float32 copy (80 MB)"""
+        ex0.record()
+        total = sm.global_map(exchange_dtype=torch.float32)
+        ex1.record()
+        return total
+
     for _ in range(args.warmup):
         step()
     if world > 1:
-        sm.global_map()
+        exchange()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     if world > 1:
-        sm.global_map()                   # the one exchange step: private grids -> shared grid (RCCL all-reduce)
+        shared = exchange()
     sync()
     elapsed = time.perf_counter() - t0
+    exchange_ms, exchange_bytes = None, None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        exchange_ms = ex0.elapsed_time(ex1)                 # cast + all-reduce on this rank's stream (the frames before it are queued ahead)
+        exchange_bytes = int(shared.numel() * shared.element_size())
+        t = torch.tensor([elapsed, exchange_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, exchange_ms = float(t[0].item()), float(t[1].item())
 
     result = None
     if rank == 0:
@@ -158,15 +175,30 @@ def main():
         if not args.no_cpu_baseline:
             parity, cpu_baseline, logits_ref = parity_and_cpu_baseline(net, state, cfg, sm.confusion_matrix, cam, image, image_host, points,
                                                                        dev, want_baseline=(world == 1))
+            # a second weights draw (the logits error follows the weights): same frame, same cloud
+            parity = {"weight_seed_0": parity}
+            for seed2 in PARITY_EXTRA_SEEDS:
+                st2 = random_state_dict(seed2)
+                net2 = SegNet(st2, H, W, precision=args.precision, device=dev, **mixed_opts)
+                parity["weight_seed_%d" % seed2] = parity_and_cpu_baseline(net2, st2, cfg, sm.confusion_matrix, cam, image, image_host, points,
+                                                                           dev, want_baseline=False)[0]
+                del net2
+                torch.cuda.empty_cache()
+            parity["worst"] = worst_parity([v for k, v in parity.items() if k.startswith("weight_seed_")])
             if world == 1 and not args.no_other_precisions:
                 other = other_precisions(args.precision, state, cfg, sm.confusion_matrix, cam, image, points, dev, logits_ref)
         result = {
             "metric": "fused frames/sec/GPU (1920x1080 + 120k pts) + max|dlog-odds| vs ref",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"mixed": "f16 (split hi+lo operands, fp32 accumulate)"}.get(args.precision, args.precision),
+            "vs_baseline": None, "dtype": {"mixed": "f16 hi+lo split, MX-FP4 correction passes, fp32 accumulate"}.get(args.precision, args.precision),
             "data": "synthetic", "per_gpu": round(fps / world, 2), "fps_incl_h2d": fps_h2d,
-            "max_abs_dlogodds_vs_oracle": None if parity is None else parity["grid_same_labels_max_abs_dlogodds"],
+            # end to end: HIP network -> HIP mapping against oracle network -> oracle mapping, worst of the weight seeds checked
+            "max_abs_dlogodds_vs_oracle": None if parity is None else parity["worst"]["grid_e2e_max_abs_dlogodds"],
+            "grid_e2e_cells_differing_frac": None if parity is None else parity["worst"]["grid_e2e_cells_differing_frac"],
+            "grid_same_labels_max_abs_dlogodds": None if parity is None else parity["worst"]["grid_same_labels_max_abs_dlogodds"],
+            "logits_max_rel_err_vs_oracle": None if parity is None else parity["worst"]["logits_max_rel_err"],
+            "exchange_ms": None if exchange_ms is None else round(exchange_ms, 3), "exchange_bytes": exchange_bytes,
             "config": {"workload": "configs[2] full fuse: seg 1920x1080 + projection + 0.2 m BEV log-odds update, 120k pts, "
                                    "2000x2000x5 f64 grid; weights random-init ResNeXt50-OS8 DeepLabV3+",
                        "precision": args.precision, "frame": [H, W], "points": NPTS, "grid": [sm.map_height, sm.map_width, sm.map_depth],
@@ -179,6 +211,19 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+PARITY_EXTRA_SEEDS = (2,)          # weight seed 2 is the worst draw of tools/seed_sweep.py
+
+
+def worst_parity(blocks):
+    """field-by-field worst of several parity blocks (max of the errors and counts, min of the agreement)"""
+    out = {}
+    for key in ("logits_max_rel_err", "label_pixels_differing", "grid_same_labels_max_abs_dlogodds", "grid_e2e_max_abs_dlogodds",
+                "grid_e2e_cells_differing", "grid_e2e_cells_differing_frac"):
+        out[key] = max(b[key] for b in blocks)
+    out["argmax_agreement"] = min(b["argmax_agreement"] for b in blocks)
+    return out
 
 
 def gemm_roofline(net, precision):
@@ -216,7 +261,8 @@ def pmc_traffic(n_gemm_launches, precision):
     --pmc passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
     16-B/lane reads on gfx950).  PMC cannot be collected inside the timed run, so this is read from
     profiles/ (tools/pmc_seg.sh regenerates it); None if no summary for this precision is committed."""
-    for rel in (os.path.join("profiles", "r02", "pmc_seg_summary_%s.json" % precision),
+    for rel in (os.path.join("profiles", "r03", "pmc_seg_summary_%s.json" % precision),
+                os.path.join("profiles", "r02", "pmc_seg_summary_%s.json" % precision),
                 os.path.join("profiles", "r01", "pmc_seg_summary.json") if precision == "bf16" else None):
         if rel and os.path.exists(os.path.join(ROOT, rel)):
             rows = [r for r in json.load(open(os.path.join(ROOT, rel))) if r["kernel"].startswith("k_gemm")]
@@ -404,6 +450,7 @@ def parity_and_cpu_baseline(net, state, cfg, cm, cam, image, image_host, points,
         "grid_same_labels_max_abs_dlogodds": float(np.max(np.abs(grid_gpu - grid_same))),
         "grid_e2e_max_abs_dlogodds": float(d_e2e.max()), "grid_e2e_cells_differing": int((d_e2e.max(axis=2) > 0).sum()),
         "grid_cells_touched": int((grid_own != 0).any(axis=2).sum()),
+        "grid_e2e_cells_differing_frac": float((d_e2e.max(axis=2) > 0).sum()) / max(1, int((grid_own != 0).any(axis=2).sum())),
         "note": "e2e = HIP network -> HIP mapping against oracle network -> oracle mapping; a grid cell differs only where a LiDAR "
                 "point lands on one of the label pixels whose arg-max flipped (near-ties within the logits tolerance)",
     }

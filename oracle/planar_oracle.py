@@ -87,7 +87,7 @@ def update_map_planar(map_local, image, points_image, anchor, map_boundary, reso
     image_on_map = warp_perspective(image, H, mw, mh)
     sep = int((8 - map_boundary[0][0]) / resolution)
     mask = np.ones((mh, mw), dtype=bool)
-    mask[:, 0:max(sep, 0)] = False
+    mask[:, 0:sep] = False                            # as written (:470): a negative sep counts from the right edge
     for i in range(len(label_names)):
         if match == "reference":
             idx = np.zeros((mh, mw), dtype=bool)          # uint8 array == str  ->  False (mapping.py:474)

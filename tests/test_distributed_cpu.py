@@ -55,9 +55,12 @@ def _worker(rank, world, port, cm_kind, q):
     total = reduce_grids(private)
     assert torch.equal(private, torch.from_numpy(grid))          # the private grid is left alone
     root_only = reduce_grids(private, dst=0)
+    # the float32 exchange copy (what bench.py --gpus N sends: half the payload)
+    total32 = reduce_grids(private, exchange_dtype=torch.float32)
+    assert total32.dtype == torch.float32 and torch.equal(private, torch.from_numpy(grid))
     if rank == 0:
         assert torch.equal(root_only, total)
-        q.put((mine, total.numpy()))
+        q.put((mine, total.numpy(), total32.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,10 +71,15 @@ def _run(cm_kind, port):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, cm_kind, q)) for r in range(2)]
     for p in procs:
         p.start()
-    mine, total = q.get()
+    mine, total, total32 = q.get()
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    # float32 exchange: exact for the integer (identity-CM) grids, one float32 rounding per rank's addend otherwise
+    assert total32.dtype == np.float32
+    assert np.max(np.abs(total32.astype(np.float64) - total)) <= 2e-7 * max(1.0, float(np.abs(total).max()))
+    if cm_kind == "eye":
+        assert np.array_equal(total32.astype(np.float64), total)
     return mine, total
 
 

@@ -129,6 +129,16 @@ def test_unpack_pointcloud2_hand_packed_buffer():
     assert np.array_equal(got2, want)
     empty = unpack_pointcloud2(_pointcloud2([]))
     assert empty.shape == (4, 0)
+    # an organised cloud (height 2) whose rows are padded to row_step, and a big-endian payload (refused, not misread)
+    flat = _pointcloud2(pts[:6])
+    rows = np.frombuffer(flat.data, dtype=np.uint8).reshape(2, 3 * 32)
+    padded = np.full((2, 3 * 32 + 20), 0xCD, dtype=np.uint8)
+    padded[:, :3 * 32] = rows
+    org = types.SimpleNamespace(**dict(vars(flat), data=padded.tobytes(), width=3, height=2, row_step=3 * 32 + 20))
+    assert np.array_equal(unpack_pointcloud2(org), unpack_pointcloud2(flat))
+    import pytest
+    with pytest.raises(NotImplementedError):
+        unpack_pointcloud2(types.SimpleNamespace(**dict(vars(flat), is_bigendian=True)))
 
 
 def test_imgmsg_decoding_handles_row_padding():

@@ -69,6 +69,59 @@ def test_hip_net_and_grid_against_oracle_net_and_grid(hw, cuda_device):
         assert differing <= 4 * flips.sum() * max(1, (H // (H // 4 - 4)) ** 2)
 
 
+def test_configs2_full_size_fused_frame_against_the_oracle(cuda_device):
+    """BASELINE configs[2] as ONE fused frame at full size -- the 1080 x 1920 frame and the 120 k-point cloud bench.py times, a
+    2000 x 2000 x 5 float64 grid at 0.2 m -- HIP network -> HIP mapping against oracle network -> oracle mapping
+    (vision_semantic_segmentation_node.py:101-116 -> mapping.py:314-319).  Asserted: logits within 1e-3; the grid IDENTICAL to
+    the oracle's given the same label map; end to end, cells may differ only through label pixels whose arg-max flipped
+    (near-ties inside the logits tolerance): at most 0.5 % of the touched cells."""
+    import torch
+    import _full_size as fs
+    from oracle import mapping_oracle as mo
+    from vision_semantic_segmentation_amd import SemanticMapping, SemanticSegmentation, get_cfg_defaults
+    from vision_semantic_segmentation_amd import synthetic as syn
+    from vision_semantic_segmentation_amd.utils.logger import MyLogger
+    H, W = fs.H, fs.W
+    img, pcd, cam = fs.bench_workload()
+    cfg = get_cfg_defaults()
+    cfg.MAPPING.BOUNDARY = syn.centred_boundary(mo.PCD_ORIGIN_OFFSET[:2], 200.0)
+    cfg.MAPPING.RESOLUTION = 0.2
+    seg = SemanticSegmentation(cfg.VISION_SEM_SEG.SEM_SEG_NETWORK, device=cuda_device, state_dict=fs.state_dict(0))
+    assert seg.precision == "mixed"
+    sm = SemanticMapping(cfg, device=cuda_device, logger=MyLogger("t", quiet=True))
+    sm.confusion_matrix = syn.log_confusion(5)
+    assert (sm.map_height, sm.map_width, sm.map_depth) == (2000, 2000, 5)
+    points = torch.from_numpy(np.ascontiguousarray(pcd.T.astype(np.float32))).to(cuda_device)       # PointCloud2 layout, as in bench.py
+    labels_dev = seg.segmentation_device(img).clone()
+    logits = seg.logits(img).float().cpu()
+    sm.frame_device(points, "velodyne", labels_dev, None, cam, src_kind="classmap", image_size=(H, W))
+    got = sm.map
+    logits_ref = fs.oracle_logits(0, "bench", H, W)
+    rel = float((logits - logits_ref).abs().max() / logits_ref.abs().max())
+    labels_ref = logits_ref.argmax(0).numpy().astype(np.uint8)
+    flips = int((labels_ref != labels_dev.cpu().numpy()).sum())
+    ocfg = dict(range_max=100.0, boundary=cfg.MAPPING.BOUNDARY, resolution=0.2, label_names=mo.LABELS_NAMES,
+                label_colors=mo.LABEL_COLORS, confusion_matrix=sm.confusion_matrix, use_pcd_intensity=True)
+    pcd64 = points.cpu().numpy().T.astype(np.float64)
+
+    def oracle_grid(lab):
+        grid = np.zeros(got.shape)
+        mo.mapping_frame(grid, pcd64, "velodyne", mo.semantic_image_from_labels(lab, H, W), None, cam.P, ocfg)
+        return grid
+
+    grid_same = oracle_grid(labels_dev.cpu().numpy())
+    grid_own = oracle_grid(labels_ref)
+    touched = int((grid_own != 0).any(axis=2).sum())
+    differing = int((np.abs(got - grid_own).max(axis=2) > 0).sum())
+    print("configs[2] fused frame: logits rel err %.3e, %d label pixels flipped, %d of %d touched cells differ end to end (max %.3f)"
+          % (rel, flips, differing, touched, float(np.abs(got - grid_own).max())))
+    assert rel <= 1e-3
+    assert touched > 10000
+    assert np.array_equal(got, grid_same)                        # float64 grid, same labels: bit for bit
+    assert differing <= 0.005 * touched
+    assert differing <= 16 * flips                               # one source pixel covers 4 x 4 image pixels: few points, few cells
+
+
 def test_hip_grid_through_the_rccl_exchange(cuda_device):
     """world_size 1 over the nccl (= RCCL) backend: a grid produced by the HIP kernels goes through
     SemanticMapping.global_map / distributed.reduce_grids unchanged; the float32 exchange copy differs by rounding only."""
@@ -86,9 +139,16 @@ def test_hip_grid_through_the_rccl_exchange(cuda_device):
         private = sm.map_dev.clone()
         total = sm.global_map()
         assert total.data_ptr() != sm.map_dev.data_ptr() and torch.equal(total, private) and torch.equal(sm.map_dev, private)
+        # the float32 exchange, bracketed by events exactly as bench.py's exchange() does for `exchange_ms` / `exchange_bytes`
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         t32 = sm.global_map(exchange_dtype=torch.float32)
-        assert t32.dtype == torch.float32
+        e1.record()
+        torch.cuda.synchronize()
+        assert t32.dtype == torch.float32 and t32.shape == private.shape and e0.elapsed_time(e1) > 0.0
+        assert int(t32.numel() * t32.element_size()) == private.numel() * 4
         assert float((t32.double() - private).abs().max()) <= 1e-6 * float(private.abs().max())
+        assert torch.equal(sm.map_dev, private)                      # the private grid keeps its float64 content
         # the collective itself, on a HIP-produced tensor
         x = private.clone()
         dist.all_reduce(x)

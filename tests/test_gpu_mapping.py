@@ -338,8 +338,8 @@ def test_pointcloud2_unpack_on_device(cuda_device):
 
 
 @pytest.mark.parametrize("match", ["reference", "colour"])
-@pytest.mark.parametrize("grid_dtype", ["f64", "f32"])
-def test_planar_mode_matches_the_restated_oracle(match, grid_dtype, cuda_device):
+@pytest.mark.parametrize("grid_dtype,x0", [("f64", -4.0), ("f32", -4.0), ("f64", 9.5)])
+def test_planar_mode_matches_the_restated_oracle(match, grid_dtype, x0, cuda_device):
     """SURVEY 8f row 2, update_map_planar (src/mapping.py:446-488; PARITY UNPINNED: OpenCV / ROS TF absent): the warp + class test +
     clamp kernel against oracle/planar_oracle.py -- float64 arithmetic in the same order on both sides, so the grids are identical."""
     import torch
@@ -352,7 +352,8 @@ def test_planar_mode_matches_the_restated_oracle(match, grid_dtype, cuda_device)
     cam = camera_setup_1().scaled(W / 1920.0, H / 1440.0)
     # the reference discretises local y as resolution * row + BOUNDARY[1][1] (mapping.py:148-152): this boundary puts the anchor
     # rectangle 16 .. 36 m ahead of the car and +-10 m to its sides, in view of camera 1
-    boundary = [[-4.0, 36.0], [-60.0, -20.0]]
+    # x0 = 9.5: the grid starts beyond x = 8 m, `sep` is negative and the reference's `mask[:, 0:sep] = 0` masks all but the last 15 columns
+    boundary = [[x0, x0 + 40.0], [-60.0, -20.0]]
     sm = make_sm(boundary, 0.1, np.eye(5), True, cuda_device, grid_dtype=grid_dtype)
     sm.planar_match = match
     image = syn.colorize(syn.make_label_map(rng, H, W, tile=16))
@@ -372,7 +373,11 @@ def test_planar_mode_matches_the_restated_oracle(match, grid_dtype, cuda_device)
     got = grid_dev.cpu().numpy().astype(np.float64)
     assert np.array_equal(got, want.astype(start.dtype).astype(np.float64))
     if match == "colour":
-        assert (want - np.maximum(start, 0)).sum() > 1000        # the warped image does land on the grid
+        votes = want - np.maximum(start, 0)
+        if x0 < 8:
+            assert votes.sum() > 1000                             # the warped image does land on the grid
+        else:
+            assert votes[:, :sm.map_width - 15].max() <= 0 and votes[:, sm.map_width - 15:].sum() > 10
     # NumPy grid (the reference's calling convention), and through mapping() with a TF stand-in
     grid_np = start.copy()
     assert sm.update_map_planar(grid_np, image, cam, T_local_to_base=T_local_to_base) is grid_np

@@ -171,17 +171,29 @@ def test_config_a_640x480_against_oracle(state, cuda_device):
 
 def test_real_camera_size_1440x1920(state, cuda_device):
     """The cameras deliver 1920x1440 (src/camera.py:114); the reference's video tool expects a 356 x 476 label map for
-    it (video_generator.py:126-127).  No oracle at this size (2.4 TFLOP on the CPU): shape, determinism, and agreement
-    between the bf16 and the fp32-input paths."""
+    it (video_generator.py:126-127).  The CPU oracle is not run at this size (2.4 TFLOP); the anchor is the fp32-input HIP path,
+    which itself sits 2e-6 from the oracle at every size the oracle is run at (test_f32_logits_within_1e3_of_oracle): the
+    DEFAULT mixed mode must stay within 1e-3 of it, and the bf16 mode within its own band."""
     import torch
     from vision_semantic_segmentation_amd import SemanticSegmentation
     img = np.random.default_rng(9).integers(0, 256, size=(1440, 1920, 3), dtype=np.uint8)
-    seg16 = SemanticSegmentation(_cfg("bf16"), device=cuda_device, state_dict=state)
-    a = seg16.segmentation(img)
-    assert a.shape == (356, 476) and a.dtype == np.int64
-    assert np.array_equal(a, seg16.segmentation(img))
     seg32 = SemanticSegmentation(_cfg("f32"), device=cuda_device, state_dict=state)
-    l16, l32 = seg16.logits(img), seg32.logits(img)
+    l32 = seg32.logits(img).clone()
+    del seg32
+    torch.cuda.empty_cache()
+    segm = SemanticSegmentation(_cfg("mixed"), device=cuda_device, state_dict=state)
+    a = segm.segmentation(img)
+    assert a.shape == (356, 476) and a.dtype == np.int64
+    assert np.array_equal(a, segm.segmentation(img))
+    lm = segm.logits(img)
+    rel = float((lm - l32).abs().max() / l32.abs().max())
+    agree = float((lm.argmax(0) == l32.argmax(0)).float().mean())
+    print("1440x1920 mixed vs f32 paths: max rel diff %.3e, argmax agreement %.5f" % (rel, agree))
+    assert rel <= 1e-3 and agree >= 0.998
+    del segm
+    torch.cuda.empty_cache()
+    seg16 = SemanticSegmentation(_cfg("bf16"), device=cuda_device, state_dict=state)
+    l16 = seg16.logits(img)
     rel = float((l16 - l32).abs().max() / l32.abs().max())
     agree = float((l16.argmax(0) == l32.argmax(0)).float().mean())
     print("1440x1920 bf16 vs f32 paths: max rel diff %.3e, argmax agreement %.5f" % (rel, agree))

@@ -37,6 +37,13 @@ def test_reference_mode_only_clamps_and_colour_mode_votes():
     assert d[:, :, [1, 3, 4]].max() == 0 and d[:, :, 0].sum() > 50 and d[:, :, 2].sum() > 50 and set(np.unique(d)) <= {0.0, 1.0}
     sep = int((8 - bnd[0][0]) / res)
     assert sep == 6 and d[:, :sep].max() == 0 and d[:, sep:].max() == 1    # columns left of `sep` are masked out (mapping.py:468-470)
+    # a grid that starts beyond x = 8 m (the reference's own BOUNDARY [[100, 300], ..]) makes sep negative: `mask[:, 0:sep] = 0` then
+    # is a from-the-right slice and masks every column except the last -sep
+    bnd2 = [[9, 19], [0, 10]]
+    sep2 = int((8 - bnd2[0][0]) / res)
+    d2 = po.update_map_planar(np.zeros_like(grid), img, pts_img, anchor, bnd2, res, mo.LABELS_NAMES, mo.LABEL_COLORS, match="colour")
+    assert sep2 == -6 and d2[:, :mw + sep2].max() == 0 and d2[:, mw + sep2:].max() == 1
+    assert np.array_equal(d2[:, mw + sep2:], d[:, mw + sep2:])               # the unmasked columns vote as before
 
 
 def test_product_host_helpers_equal_the_oracle():

@@ -166,7 +166,7 @@ def main():
     H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (96, 128)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    st = N.random_state_dict(seed=0)
+    st = N.random_state_dict(seed=int(os.environ.get("PS_SEED", "0")))
     img = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8).numpy()
     ref = NO.forward_logits(st, img)
     den = ref.abs().max().item()
@@ -309,6 +309,38 @@ def main():
         report("  + aspp dw all exact", Policy("f16", **e3))
         report("  + aspp dw all exact + stem w split + stem out exact", Policy("f16", **dict(e3, **{"stem:w": X, "stem:a": "f32"})))
         report("  + aspp dw out split only (weights f16)", Policy("f16", **dict(d, **{"aspp.b1.dw:a": "f32", "aspp.b2.dw:a": "f32", "aspp.b3.dw:a": "f32"})))
+    if sel == "r3":
+        # round 3: what is left once the grouped conv corrects for conv1's output too (MODEL.MIXED_GCONV_MX, layer2.1 onwards)?
+        def blocks(which, conv, dd):
+            for li, b in which:
+                dd["layer%d.%d.%s:a" % (li, b, conv)] = "f32"
+            return dd
+        ALL = [(li, b) for li, nb in ((1, 3), (2, 4), (3, 6), (4, 3)) for b in range(nb)]
+        MXB = [(li, b) for (li, b) in ALL if li >= 3 or (li == 2 and b >= 1)]            # blocks whose conv1 runs as an MX GEMM
+        d = {":w": "mx4", ":t": "f32", ":ta": "f32", "stem": "f16", "dec": "f32", "dec:w": "mx4",
+             "aspp.b0:a": "f32", "aspp.proj:a": "f32"}
+        for i in (1, 2, 3):
+            d["aspp.b%d.dw" % i] = "f16"
+            d["aspp.b%d.pw:a" % i] = "f32"
+        d = blocks(ALL, "conv2", d)
+        report("default (conv2 split everywhere)", Policy("f16", **d))
+        g = blocks(MXB, "conv1", dict(d))
+        report("gconv_mx: + conv1 split in MX blocks", Policy("f16", **g))
+        report("  + conv1 split in layer1, layer2.0 too", Policy("f16", **blocks(ALL, "conv1", dict(g))))
+        report("  + stem weights split", Policy("f16", **dict(g, **{"stem:w": X})))
+        report("  + stem weights split + stem out exact", Policy("f16", **dict(g, **{"stem:w": X, "stem:a": "f32"})))
+        e = dict(g)
+        for i in (1, 2, 3):
+            e["aspp.b%d.dw:a" % i] = "f32"
+        report("  + aspp dw out split", Policy("f16", **e))
+        e2 = dict(e)
+        for i in (1, 2, 3):
+            e2["aspp.b%d.dw:w" % i] = "f32"
+            e2["aspp.b%d.dw:ta" % i] = "f32"
+        report("  + aspp dw all exact", Policy("f16", **e2))
+        report("  + everything above", Policy("f16", **dict(blocks(ALL, "conv1", dict(e2)), **{"stem:w": X, "stem:a": "f32"})))
+        g6 = dict(g, **{":w": "mx6", "dec:w": "mx6"})
+        report("gconv_mx with FP6 corrections", Policy("f16", **g6))
     print("den (max|logit|) = %.3f" % den)
 
 

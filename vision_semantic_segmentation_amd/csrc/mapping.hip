@@ -307,7 +307,11 @@ __device__ __forceinline__ void cast_vote_byte_lists(unsigned* cell_mask, int* t
     const int list = blockIdx.x % kLists;
     if (threadIdx.x == 0 && wg_count > 0) wg_base = atomicAdd(&counter[kListBase + list], wg_count);
     __syncthreads();
-    if (first) touched[(long long)list * cap + wg_base + wave_off + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = cell;
+    // cap = (vote workgroups of this list) x 256 cannot overflow while the cursors start from zero; they would not after an apply
+    // launch that failed (the host then resets them, avl_fused_frame), so the append is bounded all the same: an entry
+    // past cap is dropped, never written outside the list
+    const int slot = wg_base + wave_off + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (first && slot < cap) touched[(long long)list * cap + slot] = cell;
 }
 
 // MODE: 0 = 32-bit mask + touched list, 1 = 32-bit mask only (sweep), 2 = byte mask only (sweep, see encode_vote_byte),
@@ -796,7 +800,7 @@ int launch_apply_lists(const avl_grid* g, const double* cm_host, unsigned bonus,
 
 // list (sparse) vs sweep (dense) apply: the sweep reads Hm*Wm*4 bytes whatever the cloud; the list costs a
 // returning atomic + an append per first touch.  AVL_APPLY_MODE=list|scan overrides (experiments).
-bool use_scan(const avl_grid* g, int n) {
+bool use_scan(const avl_grid* g, int n, unsigned bonus) {
     static const char* mode = getenv("AVL_APPLY_MODE");
     const long long cells = (long long)g->Hm * g->Wm;
     if (cells % 4 != 0 || (reinterpret_cast<uintptr_t>(g->cell_mask) & 15)) return false;
@@ -804,7 +808,7 @@ bool use_scan(const avl_grid* g, int n) {
     if (mode && mode[0] == 's') return true;
     // measured (32-bit sweep): sweep wins at 120 k points on 4 M cells (25 vs 36 us) and 1 M on 16 M (73 vs 213 us); the byte
     // sweep reads a quarter of that, so it stays ahead down to much sparser clouds
-    return (long long)n * (byte_mask_ok(g, 0) ? 1024 : 128) >= cells;
+    return (long long)n * (byte_mask_ok(g, bonus) ? 1024 : 128) >= cells;
 }
 
 }  // namespace
@@ -924,7 +928,7 @@ extern "C" int avl_fused_frame(const avl_grid* g, const void* pts, int n, int dt
     AVL_REQUIRE(g->touched_cap >= (n < g->Hm * g->Wm ? n : g->Hm * g->Wm), "touched_cap %d too small", g->touched_cap);
     hipStream_t s = avl::as_stream(stream);
     const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
-    const bool scan = use_scan(g, n);
+    const bool scan = use_scan(g, n, bonus_classes);
     const int mode = use_lists(g, n, bonus_classes) ? 3 : !scan ? 0 : (byte_mask_ok(g, bonus_classes) ? 2 : 1);
     if (mode == 0) AVL_HIP_CHECK(hipMemsetAsync(g->counter, 0, 16, s));      // only the single touched-list path counts there
     const int list_cap = list_geom(n).cap;
@@ -933,7 +937,13 @@ extern "C" int avl_fused_frame(const avl_grid* g, const void* pts, int n, int dt
     else { if (mode == 3) AVL_FV(AVL_SRC_CLASSMAP, 3); else if (mode == 2) AVL_FV(AVL_SRC_CLASSMAP, 2); else if (mode == 1) AVL_FV(AVL_SRC_CLASSMAP, 1); else AVL_FV(AVL_SRC_CLASSMAP, 0); }
 #undef AVL_FV
     AVL_LAUNCH_CHECK();
-    if (mode == 3) return launch_apply_lists(g, cm_host, bonus_classes, n, s);
+    if (mode == 3) {
+        rc = launch_apply_lists(g, cm_host, bonus_classes, n, s);
+        // only the apply kernel returns the list cursors to zero: if it did not launch, reset them here so that the next frame's
+        // vote appends from the start of each list again
+        if (rc != AVL_OK) (void)hipMemsetAsync(g->counter + kListBase, 0, 2 * kLists * sizeof(int), s);
+        return rc;
+    }
     if (mode == 2) return launch_sweep_bytes(g, cm_host, bonus_classes, s);
     return mode == 1 ? launch_apply_scan(g, cm_host, s) : launch_apply(g, cm_host, nullptr, 0, s);
 }

@@ -291,15 +291,23 @@ class SemanticMapping(object):
         count = torch.zeros(1, dtype=torch.int32, device=self.device)
         if n == 0:
             return points, count
+        payload = _pointcloud2_payload(msg)                   # uint8 [n * point_step]: rows without their row_step padding
         if self._pc2_stage is None or self._pc2_stage[0].numel() < nbytes:
             cap = max(nbytes, 1 << 22)
-            self._pc2_stage = (torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device))
-        host, dev = self._pc2_stage
-        host.numpy()[:nbytes] = np.frombuffer(msg.data, dtype=np.uint8, count=nbytes)       # one memcpy into pinned memory
-        dev[:nbytes].copy_(host[:nbytes], non_blocking=True)
-        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+            self._pc2_stage = (torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device),
+                               torch.cuda.Event())
+        host, dev, staged = self._pc2_stage
+        # copy and kernel are enqueued on ONE stream (the caller's, or torch's current one), so the kernel reads what the copy
+        # wrote; the pinned buffer is reused only after the previous message's copy has executed (the event), and the device
+        # staging buffer is only ever touched on that stream order
+        st = torch.cuda.current_stream(self.device) if stream is None else torch.cuda.ExternalStream(int(stream), device=self.device)
+        staged.synchronize()                                   # no-op for a never-recorded event
+        host.numpy()[:nbytes] = payload                        # one memcpy into pinned memory
+        with torch.cuda.stream(st):
+            dev[:nbytes].copy_(host[:nbytes], non_blocking=True)
+            staged.record(st)
         rc = _lib.lib().avl_unpack_pointcloud2(_ptr(dev), n, step, offs["x"], offs["y"], offs["z"], offs["intensity"], _ptr(points),
-                                               _ptr(count), C.c_void_p(s))
+                                               _ptr(count), C.c_void_p(st.cuda_stream))
         _lib.check(rc, "avl_unpack_pointcloud2")
         return points, count
 
@@ -366,15 +374,15 @@ class SemanticMapping(object):
             img = self._as_device_u8(semantic_image)
             self.update_map_planar(self.map_dev, img, camera_calibration)
             self.frames_mapped += 1
-            return
-        if self.pcd is None:
-            return
-        if self.record_inputs:                                                   # mapping.py:309-313
-            self.input_list.append({"pcd": np.array(_to_numpy(self.pcd)), "pcd_frame_id": self.pcd_frame_id,
-                                    "semantic_image": np.array(_to_numpy(semantic_image)), "pose": pose})
-        img = self._as_device_u8(semantic_image)
-        self.frame_device(self.pcd, self.pcd_frame_id, img, pose, camera_calibration, src_kind="rgb")
-        if self.save_map_to_file:                                                # mapping.py:323-345
+        else:
+            if self.pcd is None:
+                return
+            if self.record_inputs:                                               # mapping.py:309-313
+                self.input_list.append({"pcd": np.array(_to_numpy(self.pcd)), "pcd_frame_id": self.pcd_frame_id,
+                                        "semantic_image": np.array(_to_numpy(semantic_image)), "pose": pose})
+            img = self._as_device_u8(semantic_image)
+            self.frame_device(self.pcd, self.pcd_frame_id, img, pose, camera_calibration, src_kind="rgb")
+        if self.save_map_to_file:                                                # mapping.py:323-345, both depth modes
             self.save_map_to_file = False
             self.finish_run()
 
@@ -549,7 +557,10 @@ class SemanticMapping(object):
             pts_img = planar_points_image(self.anchor_points_2, self.discretize_matrix_inv, np.asarray(T_local_to_base, dtype=np.float64),
                                           self.T_velodyne_to_basklink, cam.P)
             hinv = _dbl(np.linalg.inv(find_homography(pts_img.T, self.anchor_points_2.T)))
-        sep = max(int((8 - self.map_boundary[0][0]) / self.resolution), 0)                     # :468-470
+        # :468-470 `mask[:, 0:sep] = 0` with Python's slice rules: a negative sep (map_boundary[0][0] > 8, as in the reference's
+        # own base_cfg) masks columns [0, Wm + sep), a sep beyond the width masks every column
+        sep = int((8 - self.map_boundary[0][0]) / self.resolution)
+        sep = len(range(*slice(0, sep).indices(self.map_width)))
         dt = _lib.AVL_F64 if grid_t.dtype == torch.float64 else _lib.AVL_F32
         s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         rc = _lib.lib().avl_planar_update(_ptr(grid_t), dt, self.map_height, self.map_width, self.map_depth, _ptr(img), int(img.shape[0]),
@@ -701,13 +712,29 @@ def planar_points_image(anchor, discretize_matrix_inv, T_local_to_base, T_velody
     return pi[0:2] / pi[2]
 
 
+def _pointcloud2_payload(msg):
+    """The points of a sensor_msgs/PointCloud2 as one uint8 array [width * height * point_step]: organised clouds
+    (height > 1) may pad each row to row_step, which is dropped here; big-endian payloads are refused (the reference's
+    read_points would byte-swap them; nothing on this path produces one)."""
+    if getattr(msg, "is_bigendian", False):
+        raise NotImplementedError("big-endian PointCloud2 payloads are not supported")
+    width, height, step = int(msg.width), int(msg.height), int(msg.point_step)
+    row_step = int(getattr(msg, "row_step", 0) or width * step)
+    if row_step < width * step:
+        raise ValueError("PointCloud2 row_step %d < width * point_step %d" % (row_step, width * step))
+    if height <= 1 or row_step == width * step:
+        return np.frombuffer(msg.data, dtype=np.uint8, count=width * height * step)
+    rows = np.frombuffer(msg.data, dtype=np.uint8, count=height * row_step).reshape(height, row_step)
+    return np.ascontiguousarray(rows[:, :width * step]).reshape(-1)
+
+
 def unpack_pointcloud2(msg):
     """sensor_msgs/PointCloud2 -> float64[4,N] (x,y,z,intensity), NaN points dropped
     (what mapping.py:178-180 does with a per-point loop; SURVEY Q8: the buffer is sized to the
     number of valid points instead of leaving garbage columns)."""
     offs = {f.name: f.offset for f in msg.fields}
     n = msg.width * msg.height
-    raw = np.frombuffer(msg.data, dtype=np.uint8).reshape(n, msg.point_step)
+    raw = _pointcloud2_payload(msg).reshape(n, msg.point_step)
     cols = []
     for name in ("x", "y", "z", "intensity"):
         o = offs[name]

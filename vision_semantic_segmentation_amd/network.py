@@ -374,6 +374,7 @@ class SegNet(object):
     native plan.  ``forward(image_u8_cuda)`` runs it; ``labels`` / ``logits`` are views of its outputs."""
 
     ROW_PAD = 256        # GEMM tiles read whole 128/256-row tiles
+    MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx")    # keyword switches of the "mixed" mode
 
     def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8, fuse_dwpw=True, **mixed_opts):
         assert output_stride == 8, "the reference configuration is OS8 (base_cfg.py:106)"
@@ -385,6 +386,9 @@ class SegNet(object):
         # says a single f16 rounding is too coarse: every weight is an f16 pair hi + lo, the residual trunk, the ASPP
         # outputs and the whole decoder are stored as two f16 planes, and a GEMM runs 2 or 3 MFMA passes per K block.
         self.mixed = precision == "mixed"
+        unknown = sorted(set(mixed_opts) - set(self.MIXED_OPTS))
+        if unknown:        # a typo (gconvmx=1) must not silently benchmark the default configuration
+            raise TypeError("SegNet: unknown mixed-mode option(s) %s (known: %s)" % (unknown, ", ".join(self.MIXED_OPTS)))
         self.mixed_conv1_split = self.mixed and mixed_opts.get("conv1_split", True)     # conv1 / downsample read trunk hi + lo
         self.mixed_conv2_split = self.mixed and mixed_opts.get("conv2_split", True)     # conv2 writes hi + lo, conv3 reads both
         # correction products on the block-scaled matrix cores (MX-FP4, 4x the f16 rate) wherever shapes allow (K, N % 256)
