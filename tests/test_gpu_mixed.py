@@ -444,6 +444,73 @@ def test_mx_gemm(case, cuda_device):
         assert torch.all(_unbundle(out_mx.cpu(), Mp, N, 0)[0][M:] == 0xEE)          # rows past M untouched
 
 
+@pytest.mark.parametrize("shape", [(256 * 700, 512, 512, 2), (256 * 300 + 77, 1024, 256, 1)])
+def test_mx_gemm_repeats_under_load(shape, cuda_device):
+    """Race screen for the software-pipelined MX GEMM (k_gemm_mx_pipe: LDS slots re-filled by inline-asm LDS-DMA behind a barrier
+    that sits in the middle of the MFMA stream, fragments read ahead across it): conv3-like shapes with several tiles per CU
+    (256-row tiles and, second case, 128-row tiles), both correction passes, FP4 residual and output, launched back to back
+    with copies in between, must give the same bytes every time -- and the first launch is checked against float64."""
+    import torch
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import (AVL_MX_IN_LO, AVL_MX_OUT_LO, AVL_MX_RES_LO, OP_GEMM, AvlSegOp, mx_bundle_bytes,
+                                                          mx_dequant_fp4, mx_quant_fp4, pack_mx_weights)
+    M, K, N, nmx = shape
+    Mp = (M + 255) // 256 * 256
+    g = torch.Generator().manual_seed(11)
+    a_hi = torch.randn((Mp, K), generator=g).to(torch.float16)
+    a_lo = (torch.randn((Mp, K), generator=g) * 2 ** -11).to(torch.float16)
+    r_hi = torch.randn((Mp, N), generator=g).to(torch.float16)
+    r_lo = (torch.randn((Mp, N), generator=g) * 2 ** -11).to(torch.float16)
+    w64 = torch.randn((N, K), generator=g, dtype=torch.float64) / K ** 0.5
+    w_hi16, wbundle = pack_mx_weights(w64)
+    bd = torch.randn(N, generator=g).to(cuda_device)
+    a_d, r_d = a_hi.to(cuda_device), r_hi.to(cuda_device)
+    in_mx, r_mx = _bundle(a_hi, a_lo, Mp).to(cuda_device), _bundle(r_hi, r_lo, Mp).to(cuda_device)
+    wd, wmx = w_hi16.to(cuda_device), wbundle.to(cuda_device)
+    out = torch.zeros((Mp, N), dtype=torch.float16, device=cuda_device)
+    out_mx = torch.zeros(2 * mx_bundle_bytes(Mp, N), dtype=torch.uint8, device=cuda_device)
+    op = AvlSegOp()
+    op.kind, op.dtype = OP_GEMM, _lib.AVL_F16
+    op.in_, op.out, op.weight, op.bias = a_d.data_ptr(), out.data_ptr(), wd.data_ptr(), bd.data_ptr()
+    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = 1, M, K, K, Mp
+    op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = 1, M, N, N, Mp
+    op.relu, op.w_rows, op.ksize, op.stride, op.dil, op.groups = 1, N, 1, 1, 1, 1
+    op.w_split, op.w_mx, op.in_mx, op.out_mx = 2, wmx.data_ptr(), in_mx.data_ptr(), out_mx.data_ptr()
+    op.in2, op.in2_ld, op.in2_mx = r_d.data_ptr(), N, r_mx.data_ptr()
+    op.mx_flags = (AVL_MX_IN_LO if nmx == 2 else 0) | AVL_MX_RES_LO | AVL_MX_OUT_LO
+    plan = C.c_void_p()
+    _lib.check(_lib.lib().avl_seg_plan_create((AvlSegOp * 1)(op), 1, C.byref(plan)), "avl_seg_plan_create")
+    try:
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.lib().avl_seg_plan_run(plan, s), "avl_seg_plan_run")
+        torch.cuda.synchronize()
+        ref, ref_mx = out.clone(), out_mx.clone()
+        # the first 4096 rows and the last tile against float64 (the whole product is checked at smaller sizes in test_mx_gemm)
+        deq = lambda t: mx_dequant_fp4(*mx_quant_fp4(t.double()))            # noqa: E731
+        w_hi = w64.to(torch.float16)
+        w_lo = (w64 - w_hi.double()).to(torch.float16)
+        for lo_, hi_ in ((0, 4096), (Mp - 256, M)):
+            xa, xl = a_hi[lo_:Mp if hi_ == M else hi_], a_lo[lo_:Mp if hi_ == M else hi_]
+            want = xa.double() @ w_hi.double().t() + deq(xa) @ deq(w_lo).t() + bd.cpu().double()
+            if nmx == 2:
+                want = want + deq(xl) @ deq(w_hi).t()
+            rr = r_hi[lo_:lo_ + want.shape[0]].double() + deq(r_lo[lo_:lo_ + want.shape[0]])
+            want = torch.relu(want + rr)[:hi_ - lo_]
+            got = ref[lo_:hi_].cpu().double()
+            assert float((got - want).abs().max() / want.abs().max()) <= 2 ** -11 * 1.5
+        outs = [(torch.zeros_like(out), torch.zeros_like(out_mx)) for _ in range(4)]
+        for i in range(60):
+            _lib.lib().avl_seg_plan_run(plan, s)
+            outs[i % 4][0].copy_(out)
+            outs[i % 4][1].copy_(out_mx)
+            if i % 4 == 3:
+                torch.cuda.synchronize()
+                for o, om in outs:
+                    assert torch.equal(o, ref) and torch.equal(om, ref_mx), "launch ~%d differs from the first one" % i
+    finally:
+        _lib.lib().avl_seg_plan_destroy(plan)
+
+
 @pytest.mark.parametrize("case", [(23, 45, 256, 1, 1), (30, 41, 512, 1, 2), (19, 67, 1024, 1, 4)])
 def test_grouped_conv_writes_the_mx_bundle(case, cuda_device):
     import torch

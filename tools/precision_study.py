@@ -30,6 +30,9 @@ def rnd(x, kind):
         hi = x.to(torch.float16).to(torch.float32)
         lo = (x - hi).to(torch.float16).to(torch.float32)
         return hi + lo
+    if kind in ("f16q4", "f16q6"):      # f16 plane + the lo part as an MX-FP4 / FP6 copy only (blocks of 32 channels): the trunk as stored
+        hi = x.to(torch.float16).to(torch.float32)
+        return hi + mx_quant(x - hi, 1, "fp4" if kind == "f16q4" else "fp6")
     if kind == "bf16x2":
         hi = x.to(torch.bfloat16).to(torch.float32)
         lo = (x - hi).to(torch.bfloat16).to(torch.float32)
@@ -53,6 +56,8 @@ def mx_quant(t, dim, fmt="fp4"):
     b = t.reshape(-1, 32)
     amax = b.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
     scale = torch.exp2(torch.floor(torch.log2(amax)) - 2.0)          # max / scale in [4, 8)
+    if os.environ.get("PS_SCALE", "floor") == "nosat":               # experiment: never saturate (max / scale in (3, 6])
+        scale = torch.where(amax / scale > (float(os.environ.get("PS_SAT_T", "6.0")) if fmt == "fp4" else 7.5), scale * 2, scale)
     v = (b / scale)
     if fmt == "fp4":
         grid = torch.tensor([0, 0.5, 1, 1.5, 2, 3, 4, 6.0])
@@ -309,6 +314,20 @@ def main():
         report("  + aspp dw all exact", Policy("f16", **e3))
         report("  + aspp dw all exact + stem w split + stem out exact", Policy("f16", **dict(e3, **{"stem:w": X, "stem:a": "f32"})))
         report("  + aspp dw out split only (weights f16)", Policy("f16", **dict(d, **{"aspp.b1.dw:a": "f32", "aspp.b2.dw:a": "f32", "aspp.b3.dw:a": "f32"})))
+    if sel == "r3s":
+        def blocks(which, conv, dd):
+            for li, b in which:
+                dd["layer%d.%d.%s:a" % (li, b, conv)] = "f32"
+            return dd
+        ALL = [(li, b) for li, nb in ((1, 3), (2, 4), (3, 6), (4, 3)) for b in range(nb)]
+        MXB = [(li, b) for (li, b) in ALL if li >= 3 or (li == 2 and b >= 1)]
+        d = {":w": "mx4", ":t": "f32", ":ta": "f32", "stem": "f16", "dec": "f32", "dec:w": "mx4",
+             "aspp.b0:a": "f32", "aspp.proj:a": "f32"}
+        for i in (1, 2, 3):
+            d["aspp.b%d.dw" % i] = "f16"
+            d["aspp.b%d.pw:a" % i] = "f32"
+        g = blocks(MXB, "conv1", blocks(ALL, "conv2", d))
+        report("gconv_mx, PS_SCALE=%s" % os.environ.get("PS_SCALE", "floor"), Policy("f16", **g))
     if sel == "r3":
         # round 3: what is left once the grouped conv corrects for conv1's output too (MODEL.MIXED_GCONV_MX, layer2.1 onwards)?
         def blocks(which, conv, dd):
@@ -339,6 +358,9 @@ def main():
             e2["aspp.b%d.dw:ta" % i] = "f32"
         report("  + aspp dw all exact", Policy("f16", **e2))
         report("  + everything above", Policy("f16", **dict(blocks(ALL, "conv1", dict(e2)), **{"stem:w": X, "stem:a": "f32"})))
+        report("gconv_mx, trunk stored as f16 + FP4(lo)", Policy("f16", **dict(g, **{":t": "f16q4"})))
+        report("gconv_mx, trunk stored as f16 + FP6(lo)", Policy("f16", **dict(g, **{":t": "f16q6"})))
+        report("gconv_mx, trunk f16 + FP4(lo), + aspp dw all exact", Policy("f16", **dict(e2, **{":t": "f16q4"})))
         g6 = dict(g, **{":w": "mx6", "dec:w": "mx6"})
         report("gconv_mx with FP6 corrections", Policy("f16", **g6))
     print("den (max|logit|) = %.3f" % den)

@@ -18,9 +18,13 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--top", type=int, default=25)
 ap.add_argument("--kind", default="")
 ap.add_argument("--no-conv2-split", action="store_true")
+ap.add_argument("--mixed-opts", default="", help="comma list of key=0|1 for the mixed mode (SegNet.MIXED_OPTS)")
 a = ap.parse_args()
 
-net = SegNet(random_state_dict(0), a.h, a.w, precision=a.precision, device="cuda:0", conv2_split=not a.no_conv2_split)
+opts = {kv.split("=")[0]: bool(int(kv.split("=")[1])) for kv in a.mixed_opts.split(",") if kv}
+if a.no_conv2_split:
+    opts["conv2_split"] = False
+net = SegNet(random_state_dict(0), a.h, a.w, precision=a.precision, device="cuda:0", **opts)
 img = torch.from_numpy(np.random.default_rng(1).integers(0, 256, size=(a.h, a.w, 3), dtype=np.uint8)).cuda()
 net.forward(img)
 torch.cuda.synchronize()

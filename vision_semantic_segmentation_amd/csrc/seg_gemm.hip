@@ -20,6 +20,7 @@
 //     T = float: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) -- the reference-precision mode.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "seg_types.h"
 
@@ -612,6 +613,125 @@ __device__ __forceinline__ unsigned quantize_fp4_block(const float (&v)[16], uns
     return sbyte;
 }
 
+// The epilogue of an MX GEMM tile (shared by k_gemm_ring_mx and k_gemm_mx_pipe): bias is in the accumulators; residual (one or two
+// planes), ReLU, f16 hi [+ lo] planes, and the FP4 planes + scales the next MX GEMM reads.
+template <int IO, int MI>
+__device__ __forceinline__ void mx_epilogue(const MxArgs& q, f32x4 (&acc)[MI][4], int nt, int mt, int wm, int wn, int fr, int kq) {
+    typedef f16 H;
+    typedef typename Half16<H>::v8 v8;
+    constexpr int BM = 2 * MI * 16, BN = 256;
+    const GemmArgs& p = q.g;
+    const int nbase = nt * BN + wn * 64 + kq * 16;
+    const bool ncol_ok = nbase + 16 <= p.N;
+    const bool rsplit = p.R_lo != nullptr, csplit = p.C_lo != nullptr;
+    // The epilogue is VALU-issue bound (eight rounds of ~250 vector instructions per wave while the matrix pipe idles), so:
+    // every address is a 32-bit offset from a uniform plane base (validate_gemm bounds the planes to 2 GB), the result is
+    // converted to f16 ONCE (the packed vector is stored and read back as hi), every lane stores its own 8 FP4 bytes.
+    const unsigned m0 = (unsigned)(mt * BM + wm * (MI * 16) + fr);
+    const unsigned sc_r = (unsigned)(nbase >> 8) * (unsigned)q.r_srows * 8u + (unsigned)((nbase >> 5) & 7);
+    const unsigned sc_c = (unsigned)(nbase >> 8) * (unsigned)q.c_srows * 8u + (unsigned)((nbase >> 5) & 7);
+    // the residual of row mi + 1 is requested before row mi is worked on (its loads could otherwise not move above row
+    // mi's stores, and eight dependent load -> compute -> store rounds cost more than the K loop of a short-K tile)
+    v8 nr0 = {}, nr1 = {};
+    uint2 npk = make_uint2(0u, 0u);
+    unsigned nsb = 127u;
+    auto load_res = [&](int mi) {
+        const unsigned m = m0 + mi * 16;
+        if (p.R && (int)m < p.M && ncol_ok) {
+            const H* rp = static_cast<const H*>(p.R) + (m * (unsigned)p.ldr + (unsigned)nbase);
+            nr0 = *reinterpret_cast<const v8*>(rp);
+            nr1 = *reinterpret_cast<const v8*>(rp + 8);
+            if (q.Rq) {       // the lo part as FP4: 16 values = 8 bytes, one scale byte for the lane pair's 32-block
+                npk = *reinterpret_cast<const uint2*>(q.Rq + (m * (unsigned)q.ldrq + (unsigned)(nbase / 2)));
+                nsb = (unsigned char)q.Rs[sc_r + m * 8u];
+            }
+        }
+    };
+    load_res(0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const unsigned m = m0 + mi * 16;
+        const bool live = (int)m < p.M && ncol_ok;
+        const v8 r0 = nr0, r1 = nr1;
+        const uint2 pk = npk;
+        const unsigned sb = nsb;
+        if (mi + 1 < MI) load_res(mi + 1);
+        float v[16];
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[nj * 4 + r] = acc[mi][nj][r];
+        if (p.R && live) {
+            float rl[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rl[i] = 0.f;
+            if (rsplit) {
+                const H* rlp = static_cast<const H*>(p.R_lo) + (m * (unsigned)p.ldr + (unsigned)nbase);
+                const v8 l0 = *reinterpret_cast<const v8*>(rlp), l1 = *reinterpret_cast<const v8*>(rlp + 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { rl[i] = (float)l0[i]; rl[8 + i] = (float)l1[i]; }
+            } else if (q.Rq) {
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const float sc = __uint_as_float(sb << 23);
+#define AVL_FP4_DEC(w, sel, o) { const v2f d = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, sc, sel); rl[o] = d.x; rl[o + 1] = d.y; }
+                AVL_FP4_DEC(pk.x, 0, 0) AVL_FP4_DEC(pk.x, 1, 2) AVL_FP4_DEC(pk.x, 2, 4) AVL_FP4_DEC(pk.x, 3, 6)
+                AVL_FP4_DEC(pk.y, 0, 8) AVL_FP4_DEC(pk.y, 1, 10) AVL_FP4_DEC(pk.y, 2, 12) AVL_FP4_DEC(pk.y, 3, 14)
+#undef AVL_FP4_DEC
+            }
+            // hi + lo first (exact in fp32), then the accumulator: same order as k_gemm_ring
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[i] += (float)r0[i] + rl[i]; v[8 + i] += (float)r1[i] + rl[8 + i]; }
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        v8 h0, h1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { h0[i] = (H)v[i]; h1[i] = (H)v[8 + i]; }
+        float hi[16], lo[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            hi[i] = (float)h0[i];
+            hi[8 + i] = (float)h1[i];
+            lo[i] = v[i] - hi[i];
+            lo[8 + i] = v[8 + i] - hi[8 + i];
+        }
+        const unsigned coff = m * (unsigned)p.ldc + (unsigned)nbase;
+        if (live) {
+            H* cp = static_cast<H*>(p.C) + coff;
+            *reinterpret_cast<v8*>(cp) = h0;
+            *reinterpret_cast<v8*>(cp + 8) = h1;
+        }
+        if (csplit) {          // a stored lo plane is f16: its FP4 copy is taken from what it holds
+            v8 l0, l1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { l0[i] = (H)lo[i]; l1[i] = (H)lo[8 + i]; }
+            if (live) {
+                H* cl = static_cast<H*>(p.C_lo) + coff;
+                *reinterpret_cast<v8*>(cl) = l0;
+                *reinterpret_cast<v8*>(cl + 8) = l1;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { lo[i] = (float)l0[i]; lo[8 + i] = (float)l1[i]; }
+        }
+        if constexpr (IO != 0) {
+            // every lane takes part in the block exchange; rows past M quantise whatever they hold and store nothing
+            // (the partner lane is the same row, so it is dead as well)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                if (q.Cq[pl] == nullptr) continue;
+                unsigned pq[2];
+                const unsigned sq = quantize_fp4_block(pl == 0 ? hi : lo, pq);
+                if (live) {
+                    *reinterpret_cast<uint2*>(q.Cq[pl] + (m * (unsigned)q.ldcq + (unsigned)(nbase / 2))) = make_uint2(pq[0], pq[1]);
+                    if ((kq & 1) == 0) q.Cs[pl][sc_c + m * 8u] = (char)sq;
+                }
+            }
+        }
+    }
+}
+
 // MI = 8: 256 x 256 tiles; MI = 4: 128 x 256 tiles for shapes that would otherwise leave half the CUs without a tile.
 template <int IO, int MI>
 __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
@@ -796,117 +916,283 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
                 }
             }
         }
-        // ---- epilogue: bias is in the accumulators; residual (one or two planes), ReLU, f16 hi [+ lo] planes, and the
-        // FP4 planes + scales the next MX GEMM reads
-        const int nbase = nt * BN + wn * 64 + kq * 16;
-        const bool ncol_ok = nbase + 16 <= p.N;
-        const bool rsplit = p.R_lo != nullptr, csplit = p.C_lo != nullptr;
-        // The epilogue is VALU-issue bound (eight rounds of ~250 vector instructions per wave while the matrix pipe idles), so:
-        // every address is a 32-bit offset from a uniform plane base (validate_gemm bounds the planes to 2 GB), the result is
-        // converted to f16 ONCE (the packed vector is stored and read back as hi), every lane stores its own 8 FP4 bytes.
-        const unsigned m0 = (unsigned)(mt * BM + wm * (MI * 16) + fr);
-        const unsigned sc_r = (unsigned)(nbase >> 8) * (unsigned)q.r_srows * 8u + (unsigned)((nbase >> 5) & 7);
-        const unsigned sc_c = (unsigned)(nbase >> 8) * (unsigned)q.c_srows * 8u + (unsigned)((nbase >> 5) & 7);
-        // the residual of row mi + 1 is requested before row mi is worked on (its loads could otherwise not move above row
-        // mi's stores, and eight dependent load -> compute -> store rounds cost more than the K loop of a short-K tile)
-        v8 nr0 = {}, nr1 = {};
-        uint2 npk = make_uint2(0u, 0u);
-        unsigned nsb = 127u;
-        auto load_res = [&](int mi) {
-            const unsigned m = m0 + mi * 16;
-            if (p.R && (int)m < p.M && ncol_ok) {
-                const H* rp = static_cast<const H*>(p.R) + (m * (unsigned)p.ldr + (unsigned)nbase);
-                nr0 = *reinterpret_cast<const v8*>(rp);
-                nr1 = *reinterpret_cast<const v8*>(rp + 8);
-                if (q.Rq) {       // the lo part as FP4: 16 values = 8 bytes, one scale byte for the lane pair's 32-block
-                    npk = *reinterpret_cast<const uint2*>(q.Rq + (m * (unsigned)q.ldrq + (unsigned)(nbase / 2)));
-                    nsb = (unsigned char)q.Rs[sc_r + m * 8u];
-                }
-            }
-        };
-        load_res(0);
+        mx_epilogue<IO, MI>(q, acc, nt, mt, wm, wn, fr, kq);
+        if (t + nwg < total) init_acc(t + nwg);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gemm_mx_pipe (round 3): the same tile, ring (two stages), LDS image, DMA geometry and epilogue as k_gemm_ring_mx, but the K
+// loop is ONE software-pipelined instruction stream per wave instead of "barrier, read, multiply" rounds.
+//
+// What was wrong with the rounds (ISA of k_gemm_ring_mx, round 2): after the barrier every wave read 6 fragments, waited, issued
+// 8 MFMAs, read 2 more, waited, 8 MFMAs ...: a read -> wait -> multiply chain with the LDS latency exposed every 128 cycles and
+// the whole read burst of all 8 waves exposed at every step boundary; only the SIMD partner wave could cover it, and that one
+// sat in the same chain (or in its DMA burst).  MFMA + LDS reads alone took 1.5-1.7 us per K-step against 1.06 us of MFMA issue.
+//
+// The stream (MI = 8: 16 "steps" of 4 MFMAs per sub-step; step s multiplies activation fragment mi = s % 8 of K half kk = s / 8):
+//   * fragments are read FOUR steps (256+ cycles of MFMA issue) before their MFMAs: a rolling window of activation fragments, two
+//     sets of weight fragments (the set of the other K half is read during this one);
+//   * the step boundary is moved INTO the stream: the "event" (s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier) sits in front of step 12
+//     of sub-step g.  By then every read of slot g % 2 has been issued at least two steps earlier (the last four fragments are
+//     read two per step at steps 8, 9), so the wait is free, and the barrier certifies (a) everyone's DMA of sub-step g + 1 has
+//     landed, (b) everyone is done READING slot g % 2.  Right after it the wave reads the first fragments of sub-step g + 1 from
+//     the other slot -- while it still has the 16 MFMAs of steps 12 .. 15 of sub-step g in registers to issue: the matrix pipe
+//     never waits for a barrier + a cold LDS burst;
+//   * DMA of sub-step g + 2 goes into slot g % 2 after that event: waves 4-7 ("early") issue their share right there, their SIMD
+//     partners 0-3 ("late") `late_step` steps further on, so that one wave of every SIMD issues MFMAs while the other pays the
+//     100+ cycles of issue per LDS-DMA instruction.
+// RAW / WAR on LDS (MI355X_MICROARCH.md, "Read a staged buffer one phase AFTER the wait that retires it"): a slot is read only
+// behind the barrier that follows every wave's vmcnt(0) for it; it is overwritten only by DMAs issued behind the barrier that
+// follows every wave's lgkmcnt(0) with all its reads of that slot already issued.  vmcnt(0), never a hand count.
+// Sub-step kinds (f16 / FP4) alternate inside the stream; the fragments carried across a boundary are plain 128-bit values.
+// PROBE (timing experiments, results are garbage): 1 = no DMA after the prologue, 2 = no MFMAs
+template <int IO, int MI, int LATE, int PROBE = 0>
+__global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
+    typedef f16 H;
+    typedef typename Half16<H>::v8 v8;
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    constexpr int WM = 2, WN = 4, STAGES = 2;
+    constexpr int NW = WM * WN, BM = WM * MI * 16, BN = WN * 64;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
+    constexpr int W_REGION = STAGES * A_BYTES, S_REGION = W_REGION + STAGES * W_BYTES;
+    constexpr int S_BYTES = 4096;
+    constexpr int A_INSTR = BM / 8 / NW, W_INSTR = BN / 8 / NW;
+    constexpr int NS = 2 * MI, EV = NS - 4;                     // steps per sub-step, the step in front of which the event sits
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const GemmArgs& p = q.g;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nwg = gridDim.x;
+    int vb;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3, qq = nwg >> 3, r = nwg & 7;
+        vb = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + local;
+    }
+    const int ntiles = p.ntiles, nmx = q.nmx;
+    const int total = mtiles * ntiles;
+    const int nmb = p.K / 256;
+    const int nsub = 4 + nmx;
+    const unsigned lds_base = lds_addr(lds);
+
+    // ---- producer: SGPR base + VGPR lane offset addressing.  DMA instruction i of this wave covers rows (i * 8 + wave) * 8 + srow
+    // of a tile: the (i, wave) part is uniform and goes into the scalar base, the lane keeps srow * row_bytes + its swizzled chunk
+    // ((r & 7) == srow for activation rows).  For weight rows the swizzle key ((r >> 1) & 1) | (((r >> 4) & 3) << 1) does not depend
+    // on i either (i moves r by 64): ONE lane offset per plane kind.
+    // The hot path of issue() works on a handful of scalars (cur_*: the planes of the input the current K macro-block comes from, at
+    // this tile and wave) that are re-derived from the argument struct only where they change -- at a tile switch and where the K
+    // loop passes from the first input to the second (conv3 + downsample): no scalar (kernarg) loads inside the stream, where
+    // their out-of-order lgkmcnt would force `s_waitcnt lgkmcnt(0)` in front of every LDS fragment use.
+    const int srow = lane >> 3, schunk = lane & 7;
+    const unsigned ct = (unsigned)((schunk ^ srow) << 4);
+    const int wr0 = wave * 8 + srow;
+    const unsigned wkey = (unsigned)(((wr0 >> 1) & 1) | (((wr0 >> 4) & 3) << 1));
+    const unsigned w_lane16 = (unsigned)wr0 * (unsigned)(p.K * 2) + ((schunk ^ wkey) << 4);
+    const unsigned w_laneq = (unsigned)wr0 * (unsigned)(p.K / 2) + ((schunk ^ wkey) << 4);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    int pt = vb, pmb = 0, pj = 0, issued = 0, pmbl = 0;        // tile, K macro-block (global / inside its input), sub-step being issued next
+    unsigned a_l16 = 0, a_lq = 0;                                // lane offsets into the current input's planes
+    long long cur_rowb16 = 0, cur_rowbq = 0, cur_asrows = 0;
+    const char *cur_a16 = nullptr, *cur_aq = nullptr, *cur_as = nullptr, *cur_w16 = nullptr, *cur_wq = nullptr, *cur_ws = nullptr;
+    long long cur_aps = 0, cur_wps = 0;                          // distance from correction plane 0 to plane 1 (activations / weights)
+    int p_mt = 0;
+    auto set_input = [&](bool second) __attribute__((always_inline)) {     // rare: tile switch, first -> second input
+        const long long rows0 = (long long)p_mt * BM + wave * 8;
+        if (!second) {
+            cur_rowb16 = (long long)p.lda * 2; cur_rowbq = q.ldaq; cur_asrows = q.a_srows;
+            cur_a16 = static_cast<const char*>(p.A) + rows0 * cur_rowb16;
+            cur_aq = q.Aq[0] + rows0 * cur_rowbq;
+            cur_as = q.As[0] + (long long)p_mt * BM * 8;
+            cur_aps = q.Aq[1] - q.Aq[0];
+        } else {
+            cur_rowb16 = (long long)q.lda2 * 2; cur_rowbq = q.ldaq2; cur_asrows = q.a_srows2;
+            cur_a16 = static_cast<const char*>(q.A2) + rows0 * cur_rowb16;
+            cur_aq = q.Aq2[0] + rows0 * cur_rowbq;
+            cur_as = q.As2[0] + (long long)p_mt * BM * 8;
+            cur_aps = q.Aq2[1] - q.Aq2[0];
+        }
+        a_l16 = (unsigned)srow * (unsigned)cur_rowb16 + ct;
+        a_lq = (unsigned)srow * (unsigned)cur_rowbq + ct;
+        pmbl = 0;
+    };
+    auto set_tile = [&]() __attribute__((always_inline)) {                  // rare: once per tile
+        const int nt_ = pt % ntiles;
+        p_mt = pt / ntiles;
+        cur_w16 = static_cast<const char*>(p.W) + (long long)nt_ * BN * p.K * 2;
+        cur_wq = q.Wq[0] + (long long)nt_ * BN * (p.K / 2);
+        cur_ws = q.Ws[0] + (long long)nt_ * BN * 8;
+        cur_wps = q.Wq[1] - q.Wq[0];
+        set_input(false);
+    };
+    auto issue = [&]() __attribute__((always_inline)) {
+        const unsigned abase = lds_base + (issued & 1) * A_BYTES + wave * 1024;
+        const unsigned wbase = lds_base + W_REGION + (issued & 1) * W_BYTES + wave * 1024;
+        if (pj < 4) {
+            const char* sa = cur_a16 + (long long)(pmbl * 4 + pj) * 128;
+            const char* sw = cur_w16 + (long long)(pmb * 4 + pj) * 128;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const unsigned m = m0 + mi * 16;
-            const bool live = (int)m < p.M && ncol_ok;
-            const v8 r0 = nr0, r1 = nr1;
-            const uint2 pk = npk;
-            const unsigned sb = nsb;
-            if (mi + 1 < MI) load_res(mi + 1);
-            float v[16];
+            for (int i = 0; i < A_INSTR; ++i) glds16_saddr(sa + (long long)i * (NW * 8) * cur_rowb16, a_l16, abase + i * NW * 1024);
 #pragma unroll
-            for (int nj = 0; nj < 4; ++nj)
+            for (int i = 0; i < W_INSTR; ++i) glds16_saddr(sw + (long long)i * (NW * 8) * p.K * 2, w_lane16, wbase + i * NW * 1024);
+        } else {
+            const long long ta = pj == 4 ? 0 : cur_aps, tw = pj == 4 ? 0 : cur_wps;     // which correction pass
+            const char* sa = cur_aq + ta + (long long)pmbl * 128;
+            const char* sw = cur_wq + tw + (long long)pmb * 128;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[nj * 4 + r] = acc[mi][nj][r];
-            if (p.R && live) {
-                float rl[16];
+            for (int i = 0; i < A_INSTR; ++i) glds16_saddr(sa + (long long)i * (NW * 8) * cur_rowbq, a_lq, abase + i * NW * 1024);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) rl[i] = 0.f;
-                if (rsplit) {
-                    const H* rlp = static_cast<const H*>(p.R_lo) + (m * (unsigned)p.ldr + (unsigned)nbase);
-                    const v8 l0 = *reinterpret_cast<const v8*>(rlp), l1 = *reinterpret_cast<const v8*>(rlp + 8);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { rl[i] = (float)l0[i]; rl[8 + i] = (float)l1[i]; }
-                } else if (q.Rq) {
-                    typedef float v2f __attribute__((ext_vector_type(2)));
-                    const float sc = __uint_as_float(sb << 23);
-#define AVL_FP4_DEC(w, sel, o) { const v2f d = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, sc, sel); rl[o] = d.x; rl[o + 1] = d.y; }
-                    AVL_FP4_DEC(pk.x, 0, 0) AVL_FP4_DEC(pk.x, 1, 2) AVL_FP4_DEC(pk.x, 2, 4) AVL_FP4_DEC(pk.x, 3, 6)
-                    AVL_FP4_DEC(pk.y, 0, 8) AVL_FP4_DEC(pk.y, 1, 10) AVL_FP4_DEC(pk.y, 2, 12) AVL_FP4_DEC(pk.y, 3, 14)
-#undef AVL_FP4_DEC
-                }
-                // hi + lo first (exact in fp32), then the accumulator: same order as k_gemm_ring
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { v[i] += (float)r0[i] + rl[i]; v[8 + i] += (float)r1[i] + rl[8 + i]; }
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
-            }
-            v8 h0, h1;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { h0[i] = (H)v[i]; h1[i] = (H)v[8 + i]; }
-            float hi[16], lo[16];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                hi[i] = (float)h0[i];
-                hi[8 + i] = (float)h1[i];
-                lo[i] = v[i] - hi[i];
-                lo[8 + i] = v[8 + i] - hi[8 + i];
-            }
-            const unsigned coff = m * (unsigned)p.ldc + (unsigned)nbase;
-            if (live) {
-                H* cp = static_cast<H*>(p.C) + coff;
-                *reinterpret_cast<v8*>(cp) = h0;
-                *reinterpret_cast<v8*>(cp + 8) = h1;
-            }
-            if (csplit) {          // a stored lo plane is f16: its FP4 copy is taken from what it holds
-                v8 l0, l1;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { l0[i] = (H)lo[i]; l1[i] = (H)lo[8 + i]; }
-                if (live) {
-                    H* cl = static_cast<H*>(p.C_lo) + coff;
-                    *reinterpret_cast<v8*>(cl) = l0;
-                    *reinterpret_cast<v8*>(cl + 8) = l1;
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { lo[i] = (float)l0[i]; lo[8 + i] = (float)l1[i]; }
-            }
-            if constexpr (IO != 0) {
-                // every lane takes part in the block exchange; rows past M quantise whatever they hold and store nothing
-                // (the partner lane is the same row, so it is dead as well)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    if (q.Cq[pl] == nullptr) continue;
-                    unsigned pq[2];
-                    const unsigned sq = quantize_fp4_block(pl == 0 ? hi : lo, pq);
-                    if (live) {
-                        *reinterpret_cast<uint2*>(q.Cq[pl] + (m * (unsigned)q.ldcq + (unsigned)(nbase / 2))) = make_uint2(pq[0], pq[1]);
-                        if ((kq & 1) == 0) q.Cs[pl][sc_c + m * 8u] = (char)sq;
-                    }
-                }
+            for (int i = 0; i < W_INSTR; ++i) glds16_saddr(sw + (long long)i * (NW * 8) * (p.K / 2), w_laneq, wbase + i * NW * 1024);
+            // scales: BM x 8 bytes for the activation rows (waves 0, 1: one KB each), 2 KB for the weight rows (waves 2, 3)
+            if (wave < 4 && (wave >= 2 || wave * 128 < BM)) {
+                const char* ss = wave < 2 ? cur_as + ta + (long long)pmbl * cur_asrows * 8 + wave * 1024
+                                          : cur_ws + tw + (long long)pmb * q.w_srows * 8 + (wave - 2) * 1024;
+                glds16_saddr(ss, lane16, lds_base + S_REGION + (issued & 1) * S_BYTES + wave * 1024);
             }
         }
+        ++issued;
+        if (++pj == nsub) {
+            pj = 0;
+            ++pmbl;
+            if (++pmb == nmb) {
+                pmb = 0;
+                pt += nwg;
+                if (pt < total) set_tile();
+            } else if (pmb == q.nmb1) set_input(true);
+        }
+    };
+    if (pt < total) set_tile();
+    static_assert(NW == 8, "the DMA stagger assumes waves w and w + 4 on one SIMD");
+    const bool early = wave >= 4 || q.stagger == 0;             // issues its DMAs right behind the event; the others at step LATE
+    if (pt < total) issue();                                     // sub-step 0 -> slot 0
+    if (early && pt < total) issue();                            // sub-step 1 -> slot 1 (the late waves send theirs inside sub-step 0)
+
+    // ---- consumer addressing: byte offsets inside a slot (the slot base is uniform and added per sub-step)
+    const int fr = lane & 15, kq = lane >> 4;
+    const int a_row0 = wm * (MI * 16) + fr;
+    // weight row of n-tile nj: wrow0 + 4 nj; its swizzle key ((row >> 1) & 1) | (((row >> 4) & 3) << 1) does not depend on nj, and the
+    // second K half is chunk ^ 4: one base register per operand, the rest is immediate offsets and one XOR
+    const int wrow0 = wn * 64 + (fr >> 2) * 16 + (fr & 3);
+    const int wkey_r = ((wrow0 >> 1) & 1) | (((wrow0 >> 4) & 3) << 1);
+    const unsigned a_v0 = (unsigned)(a_row0 * 128 + ((kq ^ (a_row0 & 7)) << 4));
+    const unsigned w_v0 = (unsigned)(W_REGION + wrow0 * 128 + ((kq ^ wkey_r) << 4));
+    const unsigned sa_v = (unsigned)(S_REGION + a_row0 * 8), sw_v = (unsigned)(S_REGION + 2048 + wrow0 * 8);
+    const unsigned sc_shift = 8u * (unsigned)kq;                  // this lane's K block of 32 inside a 128-wide MFMA: byte kq of the scale word
+
+    f32x4 acc[MI][4];
+    auto init_acc = [&](int t) {
+        const int nb = (t % ntiles) * BN + wn * 64 + kq * 16;
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + nb + 4 * nj);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][nj] = f32x4{b.x, b.y, b.z, b.w};
+        }
+    };
+    if (vb < total) init_acc(vb);
+
+    // fragments: step s of a sub-step uses Af[s] (and its scale word As[s]) with the weight set Wf[s / MI]
+    int4 Af[NS], Wf[2][4];
+    unsigned As[NS], Ws[2][4];
+    auto rdA = [&](const char* slot, int kk, int mi) { return *reinterpret_cast<const int4*>(slot + (a_v0 ^ (unsigned)(kk * 64)) + mi * 2048); };
+    auto rdW = [&](const char* slot, int kk, int nj) { return *reinterpret_cast<const int4*>(slot + (w_v0 ^ (unsigned)(kk * 64)) + nj * 512); };
+    auto rdAs = [&](const char* slot, int kk, int mi) { return *reinterpret_cast<const unsigned*>(slot + sa_v + mi * 128 + kk * 4); };
+    auto rdWs = [&](const char* slot, int kk, int nj) { return *reinterpret_cast<const unsigned*>(slot + sw_v + nj * 32 + kk * 4); };
+
+    int g = 0;                                                   // sub-steps consumed so far (ring position)
+    // KIND: 0 = f16 sub-step (K = 64), 1 = FP4 sub-step (K = 256, block scales); next_q: the sub-step that follows is an FP4 one
+    // (run-time, uniform: it only decides whether scale words are read ahead with the fragments -- TWO loop bodies in all, as
+    // in k_gemm_ring_mx: with a body per (kind, next kind) pair hipcc moved the accumulators between two register sets)
+    auto substep = [&](auto kind_c, const bool next_q) __attribute__((always_inline)) {
+        constexpr int KIND = decltype(kind_c)::value;
+        const char* ab = lds + (g & 1) * A_BYTES;                // a_v / w_v / s*_v carry the region offsets
+        const char* wb = lds + (g & 1) * W_BYTES;
+        const char* sb = lds + (g & 1) * S_BYTES;
+        const char* abn = lds + ((g + 1) & 1) * A_BYTES;
+        const char* wbn = lds + ((g + 1) & 1) * W_BYTES;
+        const char* sbn = lds + ((g + 1) & 1) * S_BYTES;
+        auto readA = [&](int s) {                                // fragment (and scale word) of step s of THIS sub-step
+            Af[s] = rdA(ab, s / MI, s % MI);
+            if (KIND == 1) As[s] = rdAs(sb, s / MI, s % MI);
+        };
+        auto readAn = [&](int s) {                               // ... of the NEXT sub-step (its slot, its kind)
+            Af[s] = rdA(abn, s / MI, s % MI);
+            if (next_q) As[s] = rdAs(sbn, s / MI, s % MI);
+        };
+        auto readW1 = [&](int nj) {                              // weight set of this sub-step's second K half
+            Wf[1][nj] = rdW(wb, 1, nj);
+            if (KIND == 1) Ws[1][nj] = rdWs(sb, 1, nj);
+        };
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int kk = s / MI, mi = s % MI;
+            if (s == EV) {
+                // every read of this slot was issued >= 2 steps ago; this wave's DMAs of the next sub-step have had >= 4 steps
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (PROBE != 1 && early && pt < total) issue();
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) {
+                    Wf[0][nj] = rdW(wbn, 0, nj);
+                    if (next_q) Ws[0][nj] = rdWs(sbn, 0, nj);
+                }
+                readAn(0);
+            }
+            if (PROBE != 1 && !early && s == LATE && pt < total) issue();
+            // activation fragments: four steps ahead; the last four of the slot two per step (so that they are back before the event)
+            if (s < NS - 8) readA(s + 4);
+            if (s == NS - 8) { readA(NS - 4); readA(NS - 3); }
+            if (s == NS - 7) { readA(NS - 2); readA(NS - 1); }
+            if (s >= EV && s < EV + 3) readAn(s - EV + 1);
+            // weight fragments of the second K half
+            if (MI == 8 && s >= 2 && s < 6) readW1(s - 2);
+            if (MI == 4 && s < 2) { readW1(2 * s); readW1(2 * s + 1); }
+            if (KIND == 0) {
+                const v8 af = __builtin_bit_cast(v8, Af[s]);
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) {
+                    if (PROBE == 2) asm volatile("" ::"v"(Wf[kk][nj].x), "v"(Wf[kk][nj].w), "v"(Af[s].x), "v"(Af[s].w));
+                    else acc[mi][nj] = Half16<H>::mfma(__builtin_bit_cast(v8, Wf[kk][nj]), af, acc[mi][nj]);
+                }
+            } else {
+                const v8i xa = {Af[s].x, Af[s].y, Af[s].z, Af[s].w, 0, 0, 0, 0};
+                const int as = (int)((As[s] >> sc_shift) & 0xffu);
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) {
+                    const v8i wa = {Wf[kk][nj].x, Wf[kk][nj].y, Wf[kk][nj].z, Wf[kk][nj].w, 0, 0, 0, 0};
+                    const int ws = (int)((Ws[kk][nj] >> sc_shift) & 0xffu);
+                    if (PROBE == 2) asm volatile("" ::"v"(Wf[kk][nj].x), "v"(Wf[kk][nj].w), "v"(Af[s].x), "v"(Af[s].w), "v"(ws), "v"(as));
+                    else acc[mi][nj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, acc[mi][nj], 4, 4, 0, ws, 0, as);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ++g;
+    };
+    typedef std::integral_constant<int, 0> F16;
+    typedef std::integral_constant<int, 1> FP4;
+
+    // prologue: this wave's share of sub-step 0 (and 1) has landed, then everyone's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = vb; t < total; t += nwg) {
+        const int nt = t % ntiles, mt = t / ntiles;
+        {   // cold start of the tile: the first fragments of its first sub-step (an f16 one; its slot was certified by the previous
+            // event, or by the prologue barrier).  The fragments the last sub-step of the previous tile read ahead are not kept
+            // across the epilogue (registers), they are simply read again.
+            const char* ab = lds + (g & 1) * A_BYTES;
+            const char* wb = lds + (g & 1) * W_BYTES;
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) Wf[0][nj] = rdW(wb, 0, nj);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Af[s] = rdA(ab, 0, s);
+        }
+        for (int mb = 0; mb < nmb; ++mb) {
+            for (int j = 0; j < 4; ++j) substep(F16(), j == 3);
+            for (int u = 0; u < nmx; ++u) substep(FP4(), u + 1 < nmx);
+        }
+        mx_epilogue<IO, MI>(q, acc, nt, mt, wm, wn, fr, kq);
         if (t + nwg < total) init_acc(t + nwg);
     }
 }
@@ -921,8 +1207,26 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
     const int mtiles = (a.g.M + BM - 1) / BM;
     const int total = mtiles * a.g.ntiles;
     const int grid = total < 256 ? total : 256;
-    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring_mx<IO, MI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    hipLaunchKernelGGL((k_gemm_ring_mx<IO, MI>), dim3(grid), dim3(512), LDS, s, a, mtiles);
+    static const int pipe = getenv("AVL_MX_PIPE") ? atoi(getenv("AVL_MX_PIPE")) : 1;          // 0: the round-2 kernel (A/B experiments)
+    static const int late_env = getenv("AVL_MX_LATE") ? atoi(getenv("AVL_MX_LATE")) : -1;
+    if (pipe) {
+        // LATE: the step at which waves 0-3 issue their DMAs (waves 4-7: right behind the event, step 2 MI - 4)
+        constexpr int L0 = MI == 8 ? 8 : 0, L1 = MI == 8 ? 4 : 2;
+        static const int probe = getenv("AVL_MX_PROBE") ? atoi(getenv("AVL_MX_PROBE")) : 0;       // timing experiments only (256-row tiles)
+#define AVL_PIPE_LAUNCH(...)                                                                                                                   \
+    do {                                                                                                                                       \
+        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_mx_pipe<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+        hipLaunchKernelGGL((k_gemm_mx_pipe<__VA_ARGS__>), dim3(grid), dim3(512), LDS, s, a, mtiles);                                           \
+    } while (0)
+        if (MI == 8 && probe == 1) AVL_PIPE_LAUNCH(IO, 8, 8, 1);
+        else if (MI == 8 && probe == 2) AVL_PIPE_LAUNCH(IO, 8, 8, 2);
+        else if (late_env == L1) AVL_PIPE_LAUNCH(IO, MI, L1);
+        else AVL_PIPE_LAUNCH(IO, MI, L0);
+#undef AVL_PIPE_LAUNCH
+    } else {
+        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring_mx<IO, MI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        hipLaunchKernelGGL((k_gemm_ring_mx<IO, MI>), dim3(grid), dim3(512), LDS, s, a, mtiles);
+    }
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
