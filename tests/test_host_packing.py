@@ -92,9 +92,15 @@ def test_pack_mx_weights_bundle_layout():
     ql, sl = N.mx_quant_fp4(wlo.double())
     qh, sh = N.mx_quant_fp4(whi.double())
     assert torch.equal(bundle[:256 * 128].reshape(256, 128), ql)                  # first half: Q4(W lo) then its scales
-    assert torch.equal(bundle[256 * 128:half].reshape(1, 256, 8), sl)
+    assert torch.equal(bundle[256 * 128:half].reshape(1, 256, 8), N.permute_w_scales(sl))
     assert torch.equal(bundle[half:half + 256 * 128].reshape(256, 128), qh)       # second half: Q4(W hi)
-    assert torch.equal(bundle[half + 256 * 128:].reshape(1, 256, 8), sh)
+    assert torch.equal(bundle[half + 256 * 128:].reshape(1, 256, 8), N.permute_w_scales(sh))
+    # weight scales: per 16-row block the bytes a lane of the MX GEMM needs are contiguous: [row & 3][kq][nj][kk] (seg_gemm.hip)
+    ps = N.permute_w_scales(sl).reshape(-1)
+    for row, blk32 in ((0, 0), (5, 3), (37, 6), (255, 7)):
+        b16, r16 = row // 16, row % 16
+        c, nj, kk, kq = r16 & 3, r16 >> 2, blk32 >> 2, blk32 & 3
+        assert int(ps[b16 * 128 + (c * 4 + kq) * 8 + nj * 2 + kk]) == int(sl[0, row, blk32])
 
 
 @pytest.mark.parametrize("groups", [32, 16, 8])

@@ -1,9 +1,7 @@
 #!/bin/bash
-# What bounds the software-pipelined MX GEMM?  AVL_MX_PROBE: 0 full kernel, 1 no DMA after the prologue (MFMA + LDS reads + barriers),
-# 2 no MFMAs (DMA + LDS reads + barriers).  Per-op profile of the mixed plan; layer4 conv1 / conv3 are the shapes to read.
+# Where does a wave of the software-pipelined MX GEMM spend its cycles?  AVL_MX_PROBE=3: s_memtime stamps around the two events and
+# the two DMA bursts of every sub-step, per-wave sums printed by the launcher (256-row tiles only).  Each stamp drains the wave's
+# LDS queue, so the build is slower than the real kernel: read the shares.
 OUT=${1:-gpurun_out/r3}
 mkdir -p $OUT
-for p in 0 1 2; do
-  echo "=== AVL_MX_PROBE=$p" | tee -a $OUT/probe_mx.log
-  AVL_MX_PROBE=$p python tools/profile_seg.py --precision mixed --top 14 --reps 3 2>&1 | grep -v amdgpu.ids | tee -a $OUT/probe_mx.log | grep -E "^gemm|layer4.1.conv1|layer4.1.conv3|layer3.2.conv3 |layer3.2.conv1 "
-done
+AVL_MX_PROBE=3 python tools/profile_seg.py --precision mixed --top 4 --reps 1 2>&1 | grep -v amdgpu.ids | grep "mx probe" | sort | uniq -c | sort -k4,4n -k6,6n -k8,8n | tee $OUT/probe_mx_stamps.log

@@ -586,6 +586,7 @@ struct MxArgs {
     const char* As2[2];
     long long a_srows2;
     int stagger;                // 1: waves 0-3 issue their LDS-DMAs after the first K half of a sub-step (A/B switch)
+    unsigned long long* dbg;    // AVL_MX_PROBE=3 only: per-wave cycle sums (host-visible memory), else NULL
 };
 
 // 16 values of one lane + the 16 of its partner (lane ^ 16) form one MX block: shared E8M0 scale, e2m1 elements.
@@ -893,7 +894,10 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
 #pragma unroll
                     for (int nj = 0; nj < 4; ++nj) {
                         wf[nj] = *reinterpret_cast<const int4*>(wbase + w_off[nj] + (((kk * 4 + kq) ^ w_key[nj]) << 4));
-                        ws[nj] = (int)((*reinterpret_cast<const unsigned*>(sbase + 2048 + ((w_off[nj] - W_REGION) >> 4) + kk * 4) >> (8 * kq)) & 0xffu);
+                        {   // weight scales as network.permute_w_scales lays them out: [16-row block][row & 3][kq][nj][kk]
+                            const uint2 w8 = *reinterpret_cast<const uint2*>(sbase + 2048 + (wn * 4 + (fr >> 2)) * 128 + ((fr & 3) * 4 + kq) * 8);
+                            ws[nj] = (int)(((nj < 2 ? w8.x : w8.y) >> (8 * ((nj & 1) * 2 + kk))) & 0xffu);
+                        }
                     }
                     const int achunk = ((kk * 4 + kq) ^ a_key) << 4;
                     int4 af = *reinterpret_cast<const int4*>(abase + achunk);
@@ -927,26 +931,35 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
 //
 // What was wrong with the rounds (ISA of k_gemm_ring_mx, round 2): after the barrier every wave read 6 fragments, waited, issued
 // 8 MFMAs, read 2 more, waited, 8 MFMAs ...: a read -> wait -> multiply chain with the LDS latency exposed every 128 cycles and
-// the whole read burst of all 8 waves exposed at every step boundary; only the SIMD partner wave could cover it, and that one
-// sat in the same chain (or in its DMA burst).  MFMA + LDS reads alone took 1.5-1.7 us per K-step against 1.06 us of MFMA issue.
+// the whole read burst of all 8 waves exposed at every step boundary.
 //
 // The stream (MI = 8: 16 "steps" of 4 MFMAs per sub-step; step s multiplies activation fragment mi = s % 8 of K half kk = s / 8):
-//   * fragments are read FOUR steps (256+ cycles of MFMA issue) before their MFMAs: a rolling window of activation fragments, two
-//     sets of weight fragments (the set of the other K half is read during this one);
-//   * the step boundary is moved INTO the stream: the "event" (s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier) sits in front of step 12
-//     of sub-step g.  By then every read of slot g % 2 has been issued at least two steps earlier (the last four fragments are
-//     read two per step at steps 8, 9), so the wait is free, and the barrier certifies (a) everyone's DMA of sub-step g + 1 has
-//     landed, (b) everyone is done READING slot g % 2.  Right after it the wave reads the first fragments of sub-step g + 1 from
-//     the other slot -- while it still has the 16 MFMAs of steps 12 .. 15 of sub-step g in registers to issue: the matrix pipe
-//     never waits for a barrier + a cold LDS burst;
-//   * DMA of sub-step g + 2 goes into slot g % 2 after that event: waves 4-7 ("early") issue their share right there, their SIMD
-//     partners 0-3 ("late") `late_step` steps further on, so that one wave of every SIMD issues MFMAs while the other pays the
-//     100+ cycles of issue per LDS-DMA instruction.
+//   * fragments are read D = 3 steps before their MFMAs, one activation fragment per step (a rolling window of four), two sets of
+//     weight fragments (the set of the second K half is read during steps 0-3 of the first);
+//   * the step boundaries are moved INTO the stream, and there are two per sub-step, one per LDS slot kind ("events"):
+//       EW, in front of step 5:  s_waitcnt lgkmcnt(1|2); s_barrier -- every wave has read its last WEIGHT fragment of slot g % 2:
+//                                the weight tile of sub-step g + 2 may overwrite it;
+//       EV, in front of step 13: s_waitcnt vmcnt(4) lgkmcnt(0); s_barrier -- every wave's DMAs for sub-step g + 1 have landed (only
+//                                the 4 instructions of a weight burst sent since may still fly; vmcnt(0) when none was sent) and
+//                                every wave has read its last ACTIVATION fragment of slot g % 2.  Right behind it the wave reads
+//                                the first fragments of sub-step g + 1 from the other slot -- while it still has the 12 MFMAs of
+//                                steps 13 .. 15 in registers to issue: the matrix pipe never waits for a barrier + a cold LDS burst;
+//   * one sub-step's DMA is therefore two bursts of 4 instructions per wave (weights; activations + the scale blocks of an FP4
+//     sub-step), and the bursts of the two waves of a SIMD are COMPLEMENTARY: waves 4-7 send theirs right behind EW / EV, waves 0-3
+//     one event later (right in front of EV / of the next EW), so that one wave of every SIMD issues MFMAs while the other pays
+//     the ~150 cycles per LDS-DMA instruction (s_memtime stamps, AVL_MX_PROBE=3: a 4-instruction burst takes ~600 cycles: the 16
+//     instructions of the four waves that burst together queue in the CU's one vector-memory path).
+// What bounds it now (stamps): 64 KB per sub-step through that path at ~27 B/clk = ~2400 cycles, against 2048 cycles of MFMA
+// issue per SIMD: the 256 x 256 tile is L2 -> LDS bound on this chip; the stream runs at ~3500 cycles per sub-step (was ~4000).
 // RAW / WAR on LDS (MI355X_MICROARCH.md, "Read a staged buffer one phase AFTER the wait that retires it"): a slot is read only
-// behind the barrier that follows every wave's vmcnt(0) for it; it is overwritten only by DMAs issued behind the barrier that
-// follows every wave's lgkmcnt(0) with all its reads of that slot already issued.  vmcnt(0), never a hand count.
+// behind the barrier that follows every wave's vmcnt wait for it; it is overwritten only by DMAs issued behind the barrier that
+// follows every wave's lgkmcnt wait with all its reads of that slot already issued.  The two hand counts: vmcnt(4) -- younger
+// operations (compiler-visible loads / stores, scratch) only make it wait for more; lgkmcnt(1|2) -- at least that many LDS reads
+// are issued behind the last weight read (step 4: one fragment, plus its scale byte in an FP4 sub-step).
 // Sub-step kinds (f16 / FP4) alternate inside the stream; the fragments carried across a boundary are plain 128-bit values.
-// PROBE (timing experiments, results are garbage): 1 = no DMA after the prologue, 2 = no MFMAs
+// MI = 4 (128 x 256 tiles): one event (both slots) in front of step 5 of 8, vmcnt(0).
+// PROBE (timing experiments, results are garbage): 1 = no DMA after the prologue, 2 = no MFMAs, 3 = s_memtime stamps around the
+// events and the DMA bursts, per-wave sums -> q.dbg (each stamp drains the LDS queue: read the SHARES, not the totals)
 template <int IO, int MI, int LATE, int PROBE = 0>
 __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
     typedef f16 H;
@@ -958,7 +971,8 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
     constexpr int W_REGION = STAGES * A_BYTES, S_REGION = W_REGION + STAGES * W_BYTES;
     constexpr int S_BYTES = 4096;
     constexpr int A_INSTR = BM / 8 / NW, W_INSTR = BN / 8 / NW;
-    constexpr int NS = 2 * MI, EV = NS - 4;                     // steps per sub-step, the step in front of which the event sits
+    constexpr int NS = 2 * MI, D = 3, EV = NS - D;              // steps per sub-step; fragments are read D steps ahead; the (main) event sits in front of step EV
+    constexpr int EW = MI == 8 ? 5 : EV;                         // ... and the weight-slot event (MI = 4: one event for both slots)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const GemmArgs& p = q.g;
 
@@ -985,15 +999,15 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
     // this tile and wave) that are re-derived from the argument struct only where they change -- at a tile switch and where the K
     // loop passes from the first input to the second (conv3 + downsample): no scalar (kernarg) loads inside the stream, where
     // their out-of-order lgkmcnt would force `s_waitcnt lgkmcnt(0)` in front of every LDS fragment use.
-    const int srow = lane >> 3, schunk = lane & 7;
-    const unsigned ct = (unsigned)((schunk ^ srow) << 4);
-    const int wr0 = wave * 8 + srow;
-    const unsigned wkey = (unsigned)(((wr0 >> 1) & 1) | (((wr0 >> 4) & 3) << 1));
-    const unsigned w_lane16 = (unsigned)wr0 * (unsigned)(p.K * 2) + ((schunk ^ wkey) << 4);
-    const unsigned w_laneq = (unsigned)wr0 * (unsigned)(p.K / 2) + ((schunk ^ wkey) << 4);
-    const unsigned lane16 = (unsigned)lane * 16u;
+    // The lane offsets are NOT kept in registers (the K loop has none to spare: hipcc spilled them to scratch, and a scratch reload is a
+    // vector-memory operation in the middle of the hand-counted DMA stream): every burst re-derives them from the lane id, ~8 VALU
+    // instructions beside 64 MFMAs.  The lane id comes out of a volatile asm so that the arithmetic is not hoisted back out.
+    auto lane_now = [&]() __attribute__((always_inline)) {
+        unsigned l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
     int pt = vb, pmb = 0, pj = 0, issued = 0, pmbl = 0;        // tile, K macro-block (global / inside its input), sub-step being issued next
-    unsigned a_l16 = 0, a_lq = 0;                                // lane offsets into the current input's planes
     long long cur_rowb16 = 0, cur_rowbq = 0, cur_asrows = 0;
     const char *cur_a16 = nullptr, *cur_aq = nullptr, *cur_as = nullptr, *cur_w16 = nullptr, *cur_wq = nullptr, *cur_ws = nullptr;
     long long cur_aps = 0, cur_wps = 0;                          // distance from correction plane 0 to plane 1 (activations / weights)
@@ -1013,8 +1027,6 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             cur_as = q.As2[0] + (long long)p_mt * BM * 8;
             cur_aps = q.Aq2[1] - q.Aq2[0];
         }
-        a_l16 = (unsigned)srow * (unsigned)cur_rowb16 + ct;
-        a_lq = (unsigned)srow * (unsigned)cur_rowbq + ct;
         pmbl = 0;
     };
     auto set_tile = [&]() __attribute__((always_inline)) {                  // rare: once per tile
@@ -1026,29 +1038,45 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
         cur_wps = q.Wq[1] - q.Wq[0];
         set_input(false);
     };
-    auto issue = [&]() __attribute__((always_inline)) {
-        const unsigned abase = lds_base + (issued & 1) * A_BYTES + wave * 1024;
+    // One sub-step's DMA is issued in two bursts (see the events below): the weight tile, then the activation tile (+ the scale
+    // blocks of an FP4 sub-step, so that a weight burst is W_INSTR instructions for EVERY wave: the hand count at the event).
+    auto issue_w = [&]() __attribute__((always_inline)) {
         const unsigned wbase = lds_base + W_REGION + (issued & 1) * W_BYTES + wave * 1024;
+        // weight row of instruction i: r = (i * 8 + wave) * 8 + srow; its swizzle key ((r >> 1) & 1) | (((r >> 4) & 3) << 1) =
+        // ((srow >> 1) & 1) | (((wave >> 1) & 3) << 1) does not depend on i
+        const unsigned l = lane_now(), srow = l >> 3, cw = ((l & 7u) ^ (((srow >> 1) & 1u) | (((unsigned)(wave >> 1) & 3u) << 1))) << 4;
+        const unsigned wr0 = (unsigned)wave * 8u + srow;
+        if (pj < 4) {
+            const char* sw = cur_w16 + (long long)(pmb * 4 + pj) * 128;
+            const unsigned wl = wr0 * (unsigned)(p.K * 2) + cw;
+#pragma unroll
+            for (int i = 0; i < W_INSTR; ++i) glds16_saddr(sw + (long long)i * (NW * 8) * p.K * 2, wl, wbase + i * NW * 1024);
+        } else {
+            const char* sw = cur_wq + (pj == 4 ? 0 : cur_wps) + (long long)pmb * 128;
+            const unsigned wl = wr0 * (unsigned)(p.K / 2) + cw;
+#pragma unroll
+            for (int i = 0; i < W_INSTR; ++i) glds16_saddr(sw + (long long)i * (NW * 8) * (p.K / 2), wl, wbase + i * NW * 1024);
+        }
+    };
+    auto issue_a = [&]() __attribute__((always_inline)) {
+        const unsigned abase = lds_base + (issued & 1) * A_BYTES + wave * 1024;
+        const unsigned l = lane_now(), srow = l >> 3, ct = ((l & 7u) ^ srow) << 4;        // activation rows: key = r & 7 = srow
         if (pj < 4) {
             const char* sa = cur_a16 + (long long)(pmbl * 4 + pj) * 128;
-            const char* sw = cur_w16 + (long long)(pmb * 4 + pj) * 128;
+            const unsigned al = srow * (unsigned)cur_rowb16 + ct;
 #pragma unroll
-            for (int i = 0; i < A_INSTR; ++i) glds16_saddr(sa + (long long)i * (NW * 8) * cur_rowb16, a_l16, abase + i * NW * 1024);
-#pragma unroll
-            for (int i = 0; i < W_INSTR; ++i) glds16_saddr(sw + (long long)i * (NW * 8) * p.K * 2, w_lane16, wbase + i * NW * 1024);
+            for (int i = 0; i < A_INSTR; ++i) glds16_saddr(sa + (long long)i * (NW * 8) * cur_rowb16, al, abase + i * NW * 1024);
         } else {
             const long long ta = pj == 4 ? 0 : cur_aps, tw = pj == 4 ? 0 : cur_wps;     // which correction pass
             const char* sa = cur_aq + ta + (long long)pmbl * 128;
-            const char* sw = cur_wq + tw + (long long)pmb * 128;
+            const unsigned a_lq = srow * (unsigned)cur_rowbq + ct;
 #pragma unroll
             for (int i = 0; i < A_INSTR; ++i) glds16_saddr(sa + (long long)i * (NW * 8) * cur_rowbq, a_lq, abase + i * NW * 1024);
-#pragma unroll
-            for (int i = 0; i < W_INSTR; ++i) glds16_saddr(sw + (long long)i * (NW * 8) * (p.K / 2), w_laneq, wbase + i * NW * 1024);
             // scales: BM x 8 bytes for the activation rows (waves 0, 1: one KB each), 2 KB for the weight rows (waves 2, 3)
             if (wave < 4 && (wave >= 2 || wave * 128 < BM)) {
                 const char* ss = wave < 2 ? cur_as + ta + (long long)pmbl * cur_asrows * 8 + wave * 1024
                                           : cur_ws + tw + (long long)pmb * q.w_srows * 8 + (wave - 2) * 1024;
-                glds16_saddr(ss, lane16, lds_base + S_REGION + (issued & 1) * S_BYTES + wave * 1024);
+                glds16_saddr(ss, l * 16u, lds_base + S_REGION + (issued & 1) * S_BYTES + wave * 1024);
             }
         }
         ++issued;
@@ -1064,9 +1092,9 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
     };
     if (pt < total) set_tile();
     static_assert(NW == 8, "the DMA stagger assumes waves w and w + 4 on one SIMD");
-    const bool early = wave >= 4 || q.stagger == 0;             // issues its DMAs right behind the event; the others at step LATE
-    if (pt < total) issue();                                     // sub-step 0 -> slot 0
-    if (early && pt < total) issue();                            // sub-step 1 -> slot 1 (the late waves send theirs inside sub-step 0)
+    const bool early = wave >= 4 || q.stagger == 0;             // issues its bursts right behind the events; the others LATE steps later
+    if (pt < total) { issue_w(); issue_a(); }                    // sub-step 0 -> slots 0
+    if (pt < total) { issue_w(); issue_a(); }                    // sub-step 1 -> slots 1
 
     // ---- consumer addressing: byte offsets inside a slot (the slot base is uniform and added per sub-step)
     const int fr = lane & 15, kq = lane >> 4;
@@ -1077,8 +1105,8 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
     const int wkey_r = ((wrow0 >> 1) & 1) | (((wrow0 >> 4) & 3) << 1);
     const unsigned a_v0 = (unsigned)(a_row0 * 128 + ((kq ^ (a_row0 & 7)) << 4));
     const unsigned w_v0 = (unsigned)(W_REGION + wrow0 * 128 + ((kq ^ wkey_r) << 4));
-    const unsigned sa_v = (unsigned)(S_REGION + a_row0 * 8), sw_v = (unsigned)(S_REGION + 2048 + wrow0 * 8);
-    const unsigned sc_shift = 8u * (unsigned)kq;                  // this lane's K block of 32 inside a 128-wide MFMA: byte kq of the scale word
+    const unsigned sa_v = (unsigned)(S_REGION + a_row0 * 8 + kq);
+    const unsigned sw_v = (unsigned)(S_REGION + 2048 + (wn * 4 + (fr >> 2)) * 128 + ((fr & 3) * 4 + kq) * 8);
 
     f32x4 acc[MI][4];
     auto init_acc = [&](int t) {
@@ -1092,82 +1120,145 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
     };
     if (vb < total) init_acc(vb);
 
-    // fragments: step s of a sub-step uses Af[s] (and its scale word As[s]) with the weight set Wf[s / MI]
+    // fragments: step s of a sub-step uses Af[s] (and its scale byte As[s]) with the weight set Wf[s / MI]
     int4 Af[NS], Wf[2][4];
-    unsigned As[NS], Ws[2][4];
+    unsigned As[NS];
+    uint2 Wsc = make_uint2(0u, 0u), Wsn = make_uint2(0u, 0u);    // weight scales of this / the next FP4 sub-step: byte 2 nj + kk
     auto rdA = [&](const char* slot, int kk, int mi) { return *reinterpret_cast<const int4*>(slot + (a_v0 ^ (unsigned)(kk * 64)) + mi * 2048); };
     auto rdW = [&](const char* slot, int kk, int nj) { return *reinterpret_cast<const int4*>(slot + (w_v0 ^ (unsigned)(kk * 64)) + nj * 512); };
-    auto rdAs = [&](const char* slot, int kk, int mi) { return *reinterpret_cast<const unsigned*>(slot + sa_v + mi * 128 + kk * 4); };
-    auto rdWs = [&](const char* slot, int kk, int nj) { return *reinterpret_cast<const unsigned*>(slot + sw_v + nj * 32 + kk * 4); };
+    // activation scales: the array keeps [row][8 K-blocks]; this lane's block of a 128-wide MFMA is kq + 4 kk: a byte read
+    auto rdAs = [&](const char* slot, int kk, int mi) { return (unsigned)*reinterpret_cast<const unsigned char*>(slot + sa_v + mi * 128 + kk * 4); };
+    // weight scales: the host lays them out per 16-row block as [row & 3][kq][n-tile nj][kk] (network.permute_w_scales), so the
+    // eight bytes a lane needs in a sub-step are ONE 8-byte read and the MFMA picks its byte with op_sel: no VALU, two registers
+    auto rdWs = [&](const char* slot) { return *reinterpret_cast<const uint2*>(slot + sw_v); };
 
     int g = 0;                                                   // sub-steps consumed so far (ring position)
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;      // PROBE 3: cycles in [0] sub-steps [1] EW wait [2] W burst [3] EV wait [4] A burst
+    auto stamp = [&]() __attribute__((always_inline)) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return t;
+    };
+    bool w_sent = false;                                         // this wave has issued the weight burst of the current sub-step
     // KIND: 0 = f16 sub-step (K = 64), 1 = FP4 sub-step (K = 256, block scales); next_q: the sub-step that follows is an FP4 one
-    // (run-time, uniform: it only decides whether scale words are read ahead with the fragments -- TWO loop bodies in all, as
-    // in k_gemm_ring_mx: with a body per (kind, next kind) pair hipcc moved the accumulators between two register sets)
-    auto substep = [&](auto kind_c, const bool next_q) __attribute__((always_inline)) {
-        constexpr int KIND = decltype(kind_c)::value;
-        const char* ab = lds + (g & 1) * A_BYTES;                // a_v / w_v / s*_v carry the region offsets
+    // (run-time, uniform: it only decides whether scales are read ahead with the fragments -- TWO loop bodies in all, as in
+    // k_gemm_ring_mx: with a body per (kind, next kind) pair hipcc moved the accumulators between two register sets).
+    // One step = 4 MFMAs; S is a compile-time constant (op_sel immediates, static register indices).
+    auto step = [&](auto kind_c, auto s_c, const bool next_q) __attribute__((always_inline)) {
+        constexpr int KIND = decltype(kind_c)::value, S = decltype(s_c)::value;
+        constexpr int kk = S / MI, mi = S % MI;
+        const char* ab = lds + (g & 1) * A_BYTES;                // a_v0 / w_v0 / s*_v carry the region offsets
         const char* wb = lds + (g & 1) * W_BYTES;
         const char* sb = lds + (g & 1) * S_BYTES;
         const char* abn = lds + ((g + 1) & 1) * A_BYTES;
         const char* wbn = lds + ((g + 1) & 1) * W_BYTES;
         const char* sbn = lds + ((g + 1) & 1) * S_BYTES;
-        auto readA = [&](int s) {                                // fragment (and scale word) of step s of THIS sub-step
-            Af[s] = rdA(ab, s / MI, s % MI);
-            if (KIND == 1) As[s] = rdAs(sb, s / MI, s % MI);
+        auto readA = [&](int t) {                                // fragment (and scale byte) of step t of THIS sub-step
+            Af[t] = rdA(ab, t / MI, t % MI);
+            if (KIND == 1) As[t] = rdAs(sb, t / MI, t % MI);
         };
-        auto readAn = [&](int s) {                               // ... of the NEXT sub-step (its slot, its kind)
-            Af[s] = rdA(abn, s / MI, s % MI);
-            if (next_q) As[s] = rdAs(sbn, s / MI, s % MI);
+        auto readAn = [&](int t) {                               // ... of the NEXT sub-step (its slot, its kind)
+            Af[t] = rdA(abn, t / MI, t % MI);
+            if (next_q) As[t] = rdAs(sbn, t / MI, t % MI);
         };
-        auto readW1 = [&](int nj) {                              // weight set of this sub-step's second K half
-            Wf[1][nj] = rdW(wb, 1, nj);
-            if (KIND == 1) Ws[1][nj] = rdWs(sb, 1, nj);
-        };
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int kk = s / MI, mi = s % MI;
-            if (s == EV) {
-                // every read of this slot was issued >= 2 steps ago; this wave's DMAs of the next sub-step have had >= 4 steps
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                if (PROBE != 1 && early && pt < total) issue();
-#pragma unroll
-                for (int nj = 0; nj < 4; ++nj) {
-                    Wf[0][nj] = rdW(wbn, 0, nj);
-                    if (next_q) Ws[0][nj] = rdWs(sbn, 0, nj);
-                }
-                readAn(0);
+        if (PROBE == 3 && S == 0) { const unsigned long long t = stamp(); if (tlast) tsum[0] += t - tlast; tlast = t; tsum[5] += 1; }
+        if (EW != EV && S == EW) {
+            // complementary bursts: waves 0-3 send the ACTIVATION tile of the sub-step after next here, one event after waves 4-7
+            // did (its slot was released at the previous main event; not in the very first sub-step: that tile is already in flight)
+            if (LATE == 0 && !early && g > 0 && PROBE != 1 && pt < total) {
+                unsigned long long t1 = 0;
+                if (PROBE == 3) t1 = stamp();
+                issue_a();
+                if (PROBE == 3) tsum[4] += stamp() - t1;
             }
-            if (PROBE != 1 && !early && s == LATE && pt < total) issue();
-            // activation fragments: four steps ahead; the last four of the slot two per step (so that they are back before the event)
-            if (s < NS - 8) readA(s + 4);
-            if (s == NS - 8) { readA(NS - 4); readA(NS - 3); }
-            if (s == NS - 7) { readA(NS - 2); readA(NS - 1); }
-            if (s >= EV && s < EV + 3) readAn(s - EV + 1);
-            // weight fragments of the second K half
-            if (MI == 8 && s >= 2 && s < 6) readW1(s - 2);
-            if (MI == 4 && s < 2) { readW1(2 * s); readW1(2 * s + 1); }
-            if (KIND == 0) {
-                const v8 af = __builtin_bit_cast(v8, Af[s]);
-#pragma unroll
-                for (int nj = 0; nj < 4; ++nj) {
-                    if (PROBE == 2) asm volatile("" ::"v"(Wf[kk][nj].x), "v"(Wf[kk][nj].w), "v"(Af[s].x), "v"(Af[s].w));
-                    else acc[mi][nj] = Half16<H>::mfma(__builtin_bit_cast(v8, Wf[kk][nj]), af, acc[mi][nj]);
-                }
-            } else {
-                const v8i xa = {Af[s].x, Af[s].y, Af[s].z, Af[s].w, 0, 0, 0, 0};
-                const int as = (int)((As[s] >> sc_shift) & 0xffu);
-#pragma unroll
-                for (int nj = 0; nj < 4; ++nj) {
-                    const v8i wa = {Wf[kk][nj].x, Wf[kk][nj].y, Wf[kk][nj].z, Wf[kk][nj].w, 0, 0, 0, 0};
-                    const int ws = (int)((Ws[kk][nj] >> sc_shift) & 0xffu);
-                    if (PROBE == 2) asm volatile("" ::"v"(Wf[kk][nj].x), "v"(Wf[kk][nj].w), "v"(Af[s].x), "v"(Af[s].w), "v"(ws), "v"(as));
-                    else acc[mi][nj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, acc[mi][nj], 4, 4, 0, ws, 0, as);
-                }
-            }
+            unsigned long long t0 = 0;
+            if (PROBE == 3) t0 = stamp();
+            // weight-slot event: the last weight fragment of this slot was read at step 3, in front of at least one younger LDS
+            // read (step 4: one fragment, and its scale byte in an FP4 sub-step), so lgkmcnt(1 / 2) retires every weight read
+            if (KIND == 0) asm volatile("s_waitcnt lgkmcnt(1)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t1 = 0;
+            if (PROBE == 3) { t1 = stamp(); tsum[1] += t1 - t0; }
+            if (PROBE != 1 && early && pt < total) { issue_w(); w_sent = true; }
+            if (PROBE == 3) tsum[2] += stamp() - t1;
         }
+        if (EW != EV && LATE != 0 && !early && S == EW + LATE && PROBE != 1 && pt < total) {
+            unsigned long long t1 = 0;
+            if (PROBE == 3) t1 = stamp();
+            issue_w();
+            w_sent = true;
+            if (PROBE == 3) tsum[2] += stamp() - t1;
+        }
+        if (S == EV) {
+            // every read of this slot was issued >= 2 steps ago.  DMA: the only operations this wave may still have in flight
+            // are the W_INSTR of the weight burst it issued a few steps ago (for the sub-step after next); everything older
+            // -- both tiles of the next sub-step, epilogue stores -- is waited for
+            if (EW != EV && LATE == 0 && !early && PROBE != 1 && pt < total) {
+                unsigned long long t1 = 0;
+                if (PROBE == 3) t1 = stamp();
+                issue_w();
+                w_sent = true;
+                if (PROBE == 3) tsum[2] += stamp() - t1;
+            }
+            // (no weight burst once the work has run out: then nothing may stay in flight)
+            unsigned long long t0 = 0;
+            if (PROBE == 3) t0 = stamp();
+            if (EW != EV && w_sent) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(W_INSTR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            w_sent = false;
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t1 = 0;
+            if (PROBE == 3) { t1 = stamp(); tsum[3] += t1 - t0; }
+            if (PROBE != 1 && early && pt < total) { if (EW == EV) issue_w(); issue_a(); }
+            if (PROBE == 3) tsum[4] += stamp() - t1;
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) Wf[0][nj] = rdW(wbn, 0, nj);
+            if (next_q) Wsn = rdWs(sbn);
+            readAn(0);
+        }
+        if (PROBE != 1 && !early && (EW == EV || LATE != 0) && S == EV + LATE && pt < total) {
+            unsigned long long t1 = 0;
+            if (PROBE == 3) t1 = stamp();
+            if (EW == EV) issue_w();
+            issue_a();
+            if (PROBE == 3) tsum[4] += stamp() - t1;
+        }
+        // activation fragments: D steps ahead, one per step -- the last one of the slot at step EV - 1, the first of the next slot
+        // right behind the event
+        if (S + D < NS) readA(S + D);
+        if (S >= EV && S + 1 < NS) readAn(S - EV + 1);
+        // weight fragments of the second K half
+        if constexpr (MI == 8 && S < 4) Wf[1][S] = rdW(wb, 1, S);
+        if constexpr (MI == 4 && S < 2) { Wf[1][2 * S] = rdW(wb, 1, 2 * S); Wf[1][2 * S + 1] = rdW(wb, 1, 2 * S + 1); }
+        if (KIND == 0) {
+            const v8 af = __builtin_bit_cast(v8, Af[S]);
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) {
+                if (PROBE == 2) asm volatile("" ::"v"(Wf[kk][nj].x), "v"(Wf[kk][nj].w), "v"(Af[S].x), "v"(Af[S].w));
+                else acc[mi][nj] = Half16<H>::mfma(__builtin_bit_cast(v8, Wf[kk][nj]), af, acc[mi][nj]);
+            }
+        } else {
+            const v8i xa = {Af[S].x, Af[S].y, Af[S].z, Af[S].w, 0, 0, 0, 0};
+            const int as = (int)As[S];
+#define AVL_QMFMA(NJ)                                                                                                              \
+    do {                                                                                                                           \
+        const v8i wa = {Wf[kk][NJ].x, Wf[kk][NJ].y, Wf[kk][NJ].z, Wf[kk][NJ].w, 0, 0, 0, 0};                                       \
+        const int ws = (int)((NJ) < 2 ? Wsc.x : Wsc.y);                                                                            \
+        if (PROBE == 2) asm volatile("" ::"v"(Wf[kk][NJ].x), "v"(Wf[kk][NJ].w), "v"(Af[S].x), "v"(Af[S].w), "v"(ws), "v"(as));     \
+        else acc[mi][NJ] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, acc[mi][NJ], 4, 4, ((NJ) & 1) * 2 + kk, ws, 0, as); \
+    } while (0)
+            AVL_QMFMA(0); AVL_QMFMA(1); AVL_QMFMA(2); AVL_QMFMA(3);
+#undef AVL_QMFMA
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto substep = [&](auto kind_c, const bool next_q) __attribute__((always_inline)) {
+#define AVL_STEP(N) step(kind_c, std::integral_constant<int, N>(), next_q)
+        AVL_STEP(0); AVL_STEP(1); AVL_STEP(2); AVL_STEP(3); AVL_STEP(4); AVL_STEP(5); AVL_STEP(6); AVL_STEP(7);
+        if constexpr (NS == 16) { AVL_STEP(8); AVL_STEP(9); AVL_STEP(10); AVL_STEP(11); AVL_STEP(12); AVL_STEP(13); AVL_STEP(14); AVL_STEP(15); }
+#undef AVL_STEP
+        Wsc = Wsn;                                               // (a move only where the next sub-step is an FP4 one)
         ++g;
     };
     typedef std::integral_constant<int, 0> F16;
@@ -1186,7 +1277,7 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) Wf[0][nj] = rdW(wb, 0, nj);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) Af[s] = rdA(ab, 0, s);
+            for (int s = 0; s < D; ++s) Af[s] = rdA(ab, 0, s);
         }
         for (int mb = 0; mb < nmb; ++mb) {
             for (int j = 0; j < 4; ++j) substep(F16(), j == 3);
@@ -1194,6 +1285,11 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
         }
         mx_epilogue<IO, MI>(q, acc, nt, mt, wm, wn, fr, kq);
         if (t + nwg < total) init_acc(t + nwg);
+        if (PROBE == 3) tlast = 0;                               // (the epilogue is not part of the sub-step sums)
+    }
+    if (PROBE == 3 && q.dbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = tsum[i];
     }
 }
 
@@ -1210,16 +1306,33 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
     static const int pipe = getenv("AVL_MX_PIPE") ? atoi(getenv("AVL_MX_PIPE")) : 1;          // 0: the round-2 kernel (A/B experiments)
     static const int late_env = getenv("AVL_MX_LATE") ? atoi(getenv("AVL_MX_LATE")) : -1;
     if (pipe) {
-        // LATE: the step at which waves 0-3 issue their DMAs (waves 4-7: right behind the event, step 2 MI - 4)
-        constexpr int L0 = MI == 8 ? 8 : 0, L1 = MI == 8 ? 4 : 2;
+        // LATE: how many steps behind the event(s) waves 0-3 issue their bursts (waves 4-7: right behind them)
+        constexpr int L0 = MI == 8 ? 0 : 1, L1 = 2;
         static const int probe = getenv("AVL_MX_PROBE") ? atoi(getenv("AVL_MX_PROBE")) : 0;       // timing experiments only (256-row tiles)
 #define AVL_PIPE_LAUNCH(...)                                                                                                                   \
     do {                                                                                                                                       \
         AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_mx_pipe<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
         hipLaunchKernelGGL((k_gemm_mx_pipe<__VA_ARGS__>), dim3(grid), dim3(512), LDS, s, a, mtiles);                                           \
     } while (0)
-        if (MI == 8 && probe == 1) AVL_PIPE_LAUNCH(IO, 8, 8, 1);
-        else if (MI == 8 && probe == 2) AVL_PIPE_LAUNCH(IO, 8, 8, 2);
+        if (MI == 8 && probe == 1) AVL_PIPE_LAUNCH(IO, 8, 0, 1);
+        else if (MI == 8 && probe == 2) AVL_PIPE_LAUNCH(IO, 8, 0, 2);
+        else if (MI == 8 && probe == 3) {
+            static unsigned long long* dbg = nullptr;
+            if (!dbg) AVL_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&dbg), 256 * 8 * 8 * sizeof(unsigned long long), 0));
+            memset(dbg, 0, 256 * 8 * 8 * sizeof(unsigned long long));
+            a.dbg = dbg;
+            AVL_PIPE_LAUNCH(IO, 8, 0, 3);
+            AVL_HIP_CHECK(hipStreamSynchronize(s));
+            double sum[2][8] = {};
+            for (int b = 0; b < grid; ++b)
+                for (int w = 0; w < 8; ++w)
+                    for (int i = 0; i < 8; ++i) sum[w >= 4][i] += (double)dbg[(b * 8 + w) * 8 + i];
+            for (int e = 0; e < 2; ++e) {
+                const double n = sum[e][5] > 0 ? sum[e][5] : 1;
+                fprintf(stderr, "[mx probe] M %d N %d K %d nmx %d %s waves: cycles per sub-step %.0f | EW wait+barrier %.0f | W burst %.0f | EV wait+barrier %.0f | A burst %.0f\n",
+                        a.g.M, a.g.N, a.g.K, a.nmx, e ? "early (4-7)" : "late (0-3)", sum[e][0] / n, sum[e][1] / n, sum[e][2] / n, sum[e][3] / n, sum[e][4] / n);
+            }
+        }
         else if (late_env == L1) AVL_PIPE_LAUNCH(IO, MI, L1);
         else AVL_PIPE_LAUNCH(IO, MI, L0);
 #undef AVL_PIPE_LAUNCH
@@ -1281,8 +1394,8 @@ int validate_gemm(const avl_seg_op& op) {
         AVL_REQUIRE(!(op.mx_flags & AVL_MX_OUT_LO) || op.out_mx, "AVL_MX_OUT_LO without out_mx");
         AVL_REQUIRE(!(op.mx_flags & AVL_MX_IN_LO) || !op.in_lo, "AVL_MX_IN_LO together with in_lo");
         if (op.in3) {
-            AVL_REQUIRE(op.in3_mx && op.in3_c > 0 && op.in3_c % 256 == 0 && op.in3_ld >= op.in3_c && (op.in3_ld * 2) % 16 == 0,
-                        "second GEMM input: in3_mx, in3_c %d (multiple of 256), in3_ld %d", op.in3_c, op.in3_ld);
+            AVL_REQUIRE(op.in3_mx && op.in3_c > 0 && op.in3_c % 256 == 0 && op.in3_ld == op.in3_c,
+                        "second GEMM input: in3_mx, in3_c %d (multiple of 256), dense rows (in3_ld %d)", op.in3_c, op.in3_ld);
             AVL_REQUIRE(!op.in_lo || (op.mx_flags & AVL_MX_IN_LO), "a second GEMM input needs both inputs' lo parts in their bundles (AVL_MX_IN_LO) or none");
             AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.in3) | reinterpret_cast<uintptr_t>(op.in3_mx)) % 16 == 0, "second GEMM input must be 16-byte aligned");
         }

@@ -345,12 +345,24 @@ def mx_bundle_bytes(rows, c):
     return rows * (c // 2) + (c // 256) * rows * 8
 
 
+def permute_w_scales(scales):
+    """WEIGHT scales of an MX GEMM, uint8 [K/256][rows][8] (rows % 16 == 0) -> the same bytes re-ordered inside every 16-row block
+    as [row & 3][kq][nj][kk] (row = 16 blk + 4 nj + (row & 3), K block of 32 = 4 kk + kq): the eight scale bytes one lane of
+    k_gemm_mx_pipe needs in a sub-step (n-tiles nj = 0..3 x K halves kk = 0, 1 for its row & 3 and its kq) are then 8 contiguous
+    bytes -- one LDS read, the byte picked by the MFMA's op_sel (seg_gemm.hip).  Activation scales keep the plain layout."""
+    nb, rows, _ = scales.shape
+    assert rows % 16 == 0
+    s = scales.reshape(nb, rows // 16, 4, 4, 2, 4)             # [mb][blk][nj][c = row & 3][kk][kq]
+    return s.permute(0, 1, 3, 5, 2, 4).contiguous().reshape(nb, rows, 8)
+
+
 def pack_mx_weights(w):
-    """float64 [w_rows][K] -> (f16 hi plain rows, uint8 bundle [Q4(W lo) | scales | Q4(W hi) | scales])"""
+    """float64 [w_rows][K] -> (f16 hi plain rows, uint8 bundle [Q4(W lo) | scales | Q4(W hi) | scales]); the scales in the
+    per-lane order of permute_w_scales"""
     hi, lo = split_f16(w)
     ql, sl = mx_quant_fp4(lo.to(torch.float64))
     qh, sh = mx_quant_fp4(hi.to(torch.float64))
-    return hi, torch.cat([ql.reshape(-1), sl.reshape(-1), qh.reshape(-1), sh.reshape(-1)])
+    return hi, torch.cat([ql.reshape(-1), permute_w_scales(sl).reshape(-1), qh.reshape(-1), permute_w_scales(sh).reshape(-1)])
 
 
 class Act(object):
