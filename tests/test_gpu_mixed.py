@@ -181,6 +181,56 @@ def test_split_fused_depthwise_pointwise(case, cuda_device):
     assert torch.all(out[:, M:] == 7.0)
 
 
+@pytest.mark.parametrize("case", [(37, 53, 128, 256, 12), (20, 31, 2048, 256, 24), (16, 16, 256, 512, 1), (45, 80, 2048, 256, 36)])
+def test_exact_fused_depthwise_pointwise(case, cuda_device):
+    """AVL_OP_DWPW with w_split = 2 (k_dwpw_x, the ASPP branches of the default mixed mode): depthwise weights as f16 pairs, the
+    depthwise result as an f16 hi + lo tile, three MFMA passes -- against a float64 evaluation of the SAME operands (the f16
+    input plane; the weights hi + lo): nothing but fp32 accumulation is rounded away."""
+    import torch
+    import torch.nn.functional as F
+    from test_gpu_ops import _from_rows, _nhwc_rows
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import OP_DWPW, AvlSegOp, dwpw_tile_order, pack_dw_pairs_split, pack_split_rows, split_f16
+    H, W, K, N, d = case
+    g = torch.Generator().manual_seed(H * 31 + W + K + d + 1)
+    x = torch.randn((1, K, H, W), generator=g).to(torch.float16)
+    w1 = (torch.randn((K, 1, 3, 3), generator=g) * 0.3).double()
+    b1 = (torch.randn(K, generator=g) * 0.1).double()
+    w2 = torch.randn((N, K), generator=g, dtype=torch.float64) / K ** 0.5
+    b2 = torch.randn(N, generator=g) * 0.1
+    M = H * W
+    Mp, Np = (M + 255) // 256 * 256, (N + 255) // 256 * 256
+    src = _nhwc_rows(x).to(cuda_device)
+    w2p = torch.zeros((Np, K), dtype=torch.float64)
+    w2p[:N] = w2
+    b2p = torch.zeros(Np)
+    b2p[:N] = b2
+    w2d, b2d = pack_split_rows(w2p, 2).to(cuda_device), b2p.to(cuda_device)
+    out = torch.full((2, Mp, N), 7.0, dtype=torch.float16, device=cuda_device)
+    params = torch.cat([pack_dw_pairs_split(w1, b1), dwpw_tile_order(H, W, d)]).to(cuda_device)
+    op = AvlSegOp()
+    op.kind, op.dtype = OP_DWPW, _lib.AVL_F16
+    op.in_, op.in2, op.out, op.out_lo = src.data_ptr(), params.data_ptr(), out[0].data_ptr(), out[1].data_ptr()
+    op.weight, op.bias, op.w_split = w2d.data_ptr(), b2d.data_ptr(), 2
+    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = H, W, K, K, src.shape[0]
+    op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = H, W, N, N, Mp
+    op.relu, op.w_rows, op.ksize, op.stride, op.pad, op.dil, op.groups = 1, Np, 3, 1, d, d, K
+    _run_plan([op])
+    w1h, w1l = split_f16(w1.reshape(K, 9))
+    w1s = (w1h.double() + w1l.double()).reshape(K, 1, 3, 3)                  # what the kernel multiplies with
+    b1s = b1.to(torch.float32).double()
+    a64 = F.relu(F.conv2d(x.double(), w1s, b1s, padding=d, dilation=d, groups=K))
+    ah, al = _split(a64)                                                      # the tile the kernel keeps: f16 hi + f16 lo
+    w_hi, w_lo = _split(w2)
+    ref = F.relu(F.conv2d(ah.double() + al.double(), (w_hi.double() + w_lo.double()).view(N, K, 1, 1), b2.double()))
+    got = _from_rows(out[0].cpu().double() + out[1].cpu().double(), H, W, N)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print("exact dwpw %s: %.3e" % (case, err))
+    # fp32 accumulation of the depthwise sums before the hi / lo split (2^-24 relative each) and of K products: TOL-sized
+    assert err <= 2 * TOL, "exact dwpw %s: %.3e" % (case, err)
+    assert torch.all(out[:, M:] == 7.0)
+
+
 @pytest.mark.parametrize("case", [(37, 53, 64, 1, 0), (20, 31, 512, 1, 0), (9, 9, 64, 2, 2)])
 def test_split_depthwise_and_bilinear(case, cuda_device):
     import torch
@@ -314,22 +364,26 @@ def test_mixed_logits_across_weight_seeds(wseed, iseed, h, w, cuda_device):
     assert agree >= 0.998
 
 
-def test_mixed_logits_with_the_mx_grouped_conv(state, cuda_device):
-    """MODEL.MIXED_GCONV_MX = True (FP4 corrections inside the grouped 3x3 as well): same 1e-3 bound, through the cfg switch."""
+def test_mixed_logits_without_the_mx_grouped_conv(state, cuda_device):
+    """MODEL.MIXED_GCONV_MX = False (the round-2 default: conv1's output as one f16 plane, the grouped 3x3 with split weights only):
+    still inside 1e-3 on these weights (not on every draw: that is why it is no longer the default), through the cfg switch."""
     import numpy as np
     from oracle import network_oracle as no
     from test_gpu_seg import _cfg
     from vision_semantic_segmentation_amd import SemanticSegmentation
+    from vision_semantic_segmentation_amd.network import OP_GCONV
     cfg = _cfg("mixed")
-    cfg.MODEL.MIXED_GCONV_MX = True
+    assert cfg.MODEL.MIXED_GCONV_MX is True                                # the default: FP4 corrections inside the grouped conv
+    seg_default = SemanticSegmentation(cfg, device=cuda_device, state_dict=state)
+    assert any(op.w_split == 2 and op.kind == OP_GCONV for op in seg_default.net_for(320, 416).ops)
+    cfg.MODEL.MIXED_GCONV_MX = False
     seg = SemanticSegmentation(cfg, device=cuda_device, state_dict=state)
     img = np.random.default_rng(0).integers(0, 256, size=(320, 416, 3), dtype=np.uint8)
     got = seg.logits(img).cpu()
-    from vision_semantic_segmentation_amd.network import OP_GCONV
-    assert any(op.w_split == 2 and op.kind == OP_GCONV for op in seg.net_for(320, 416).ops)
+    assert not any(op.w_split == 2 and op.kind == OP_GCONV for op in seg.net_for(320, 416).ops)
     ref = no.forward_logits(state, img)[0]
     rel = float((got - ref).abs().max() / ref.abs().max())
-    print("mixed + MX grouped conv 320x416: max rel err %.3e" % rel)
+    print("mixed without the MX grouped conv 320x416: max rel err %.3e" % rel)
     assert rel <= 1e-3
 
 

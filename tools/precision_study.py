@@ -56,8 +56,8 @@ def mx_quant(t, dim, fmt="fp4"):
     b = t.reshape(-1, 32)
     amax = b.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
     scale = torch.exp2(torch.floor(torch.log2(amax)) - 2.0)          # max / scale in [4, 8)
-    if os.environ.get("PS_SCALE", "floor") == "nosat":               # experiment: never saturate (max / scale in (3, 6])
-        scale = torch.where(amax / scale > (float(os.environ.get("PS_SAT_T", "6.0")) if fmt == "fp4" else 7.5), scale * 2, scale)
+    if os.environ.get("PS_SCALE", "bump") == "bump":                 # the rule the kernels use (seg_types.h mx_fp4_scale_byte); "floor": OCP's
+        scale = torch.where(amax / scale > (float(os.environ.get("PS_SAT_T", "6.5")) if fmt == "fp4" else 7.5), scale * 2, scale)
     v = (b / scale)
     if fmt == "fp4":
         grid = torch.tensor([0, 0.5, 1, 1.5, 2, 3, 4, 6.0])

@@ -318,8 +318,7 @@ __global__ void __launch_bounds__(kThreads) k_dwconv(const T* __restrict__ in, c
                     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(src[i]));
                     amax = fmaxf(amax, __shfl_xor(amax, 1));
                     amax = fmaxf(amax, __shfl_xor(amax, 2));
-                    const unsigned e = __float_as_uint(amax) >> 23;
-                    const unsigned sbyte = e >= 3u ? e - 2u : 1u;
+                    const unsigned sbyte = mx_fp4_scale_byte(amax);
                     const float scale = __uint_as_float(sbyte << 23);
                     unsigned pk = 0u;
                     pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[0], src[1], scale, 0);

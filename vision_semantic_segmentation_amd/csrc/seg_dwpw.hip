@@ -248,6 +248,249 @@ __global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_dwpw_x: the "mixed" precision variant with an EXACT depthwise stage (round 3).
+// Measured on the worst weights draw at 1080p (tools/opt_sweep.py): the two roundings the fused kernel above adds to the split
+// pipeline -- depthwise weights as ONE f16 each, the depthwise result as ONE f16 plane in LDS -- carried 47 % of the logits' error
+// energy (rms 1.59e-4 -> 1.16e-4 with the branches run unfused through the split depthwise kernel; weights 2/3 of it, result 1/3).
+// Here: depthwise weights as f16 PAIRS hi + lo (two v_dot2c per tap pair), the result split into an f16 hi tile and an f16 lo tile
+// in LDS, and three MFMA passes per 64-wide K-step: Wh.th + Wh.tl (sub-step j = 0, weight slice hi) and Wl.th (j = 1, slice lo).
+//   LDS: weight ring 2 x 32 KB | hi tiles 2 x 16 KB | lo tile 16 KB (written in sub-step j = 1 of step s - 1, read in j = 0 of
+//   step s) | a ring of four K-steps' depthwise parameters (11 rows x 8 dwords per 8-channel chunk: 5 tap pairs hi, 5 lo, bias),
+//   refilled three steps ahead by the first 176 lanes: with hi + lo the parameters of all K-steps (88 KB) no longer fit.
+//   The whole depthwise slice s + 1 is computed during sub-step j = 1 (32 MFMAs), j = 0 carries 64 MFMAs.
+constexpr int X_LDS_W = 0, X_LDS_AH = 2 * W_STAGE, X_LDS_AL = X_LDS_AH + 2 * A_STAGE, X_LDS_P = X_LDS_AL + A_STAGE;
+constexpr int XP_STEP = 8 * 11 * 8 * 4;             // 2816 bytes of depthwise parameters per K-step
+constexpr int XP_RING = 4;
+
+__global__ void __launch_bounds__(512) k_dwpw_x(DwPwArgs p) {
+    typedef f16 HT;
+    typedef typename Half16<HT>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nt = blockIdx.x % p.ntiles;
+    const int bm = blockIdx.x / p.ntiles, slot = (bm & 7) * p.per_xcd + (bm >> 3);
+    if (slot >= p.mtiles) return;
+    const int mt = p.order[slot];
+    const int nk = p.K / 64;
+
+    // ---- depthwise parameters: K-step s -> ring slot s & 3, 176 lanes x 16 bytes
+    const uint4* psrc = reinterpret_cast<const uint4*>(p.dwp);
+    uint4 pnext = make_uint4(0u, 0u, 0u, 0u);
+    auto load_p = [&](int s) { if (tid < XP_STEP / 16 && s < nk) pnext = psrc[s * (XP_STEP / 16) + tid]; };
+    auto store_p = [&](int s) { if (tid < XP_STEP / 16 && s < nk) *reinterpret_cast<uint4*>(lds + X_LDS_P + (s & (XP_RING - 1)) * XP_STEP + tid * 16) = pnext; };
+    for (int s = 0; s < 3; ++s) { load_p(s); store_p(s); }
+
+    // ---- producer geometry: lane -> 8-channel chunk of two pixels (rows r0, r0 + 64 of the tile)
+    const int chunk = tid & 7, r0 = tid >> 3;
+    unsigned voff[2][9];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int m = mt * TM + r0 + q * 64;
+        const int y = m / p.OW, x = m - y * p.OW;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = y - p.pad + (t / 3) * p.dil, ix = x - p.pad + (t % 3) * p.dil;
+            const bool ok = m < p.M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd;
+            voff[q][t] = ok ? (unsigned)(((long long)iy * p.Wd + ix) * p.ldx + chunk * 8) * 2u : 0x7fffff00u;   // >= x_bytes: reads as 0
+        }
+    }
+    // ---- pointwise weight sub-slices (256 rows x 128 B) through registers, as in k_dwpw: rows [K/64][hi 64 | lo 64]
+    const int wchunk = tid & 7, wrow0 = tid >> 3;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(p.W) + (long long)nt * TN * p.K * 4), 0, TN * p.K * 4, 0x00020000);
+    int w_voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w_voff[i] = (wrow0 + 64 * i) * p.K * 4 + wchunk * 16;
+    v4i wl[4];
+    auto load_w = [&](int h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wl[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff[i], h * 128, 0);
+    };
+    auto store_w = [&](int h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = wrow0 + 64 * i;
+            const int key = ((r >> 1) & 1) | (((r >> 4) & 3) << 1);
+            *reinterpret_cast<v4i*>(lds + X_LDS_W + (h & 1) * W_STAGE + r * 128 + ((wchunk ^ key) << 4)) = wl[i];
+        }
+    };
+
+    // ---- consumer geometry (64 x 64 per wave, product transposed: a lane ends with 16 consecutive channels of a pixel)
+    const int fr = lane & 15, kq = lane >> 4;
+    int a_off[4], w_off[4], a_key[4], w_key[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int row = wm * 64 + mi * 16 + fr;
+        a_off[mi] = row * 128;
+        a_key[mi] = row & 7;
+    }
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) {
+        const int row = wn * 64 + (fr >> 2) * 16 + nj * 4 + (fr & 3);
+        w_off[nj] = X_LDS_W + row * 128;
+        w_key[nj] = ((row >> 1) & 1) | (((row >> 4) & 3) << 1);
+    }
+    f32x4 acc[4][4];
+    {
+        const int nb = nt * TN + wn * 64 + kq * 16;
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + nb + 4 * nj);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[mi][nj] = f32x4{b.x, b.y, b.z, b.w};
+        }
+    }
+
+    v4i raw[2][9];
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.X), 0, (int)p.x_bytes, 0x00020000);
+    auto load_taps = [&](int s, int q) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) raw[q][t] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)voff[q][t], s * 128, 0);
+    };
+
+    // depthwise 3x3 of K-step s for pixel q of this lane: fp32 sums of f16 x (f16 hi + f16 lo) products -> hi tile slot s & 1, lo tile
+    auto produce_a = [&](int s, int q) {
+        const uint32_t* pp = reinterpret_cast<const uint32_t*>(lds + X_LDS_P + (s & (XP_RING - 1)) * XP_STEP + chunk * (11 * 8 * 4));
+        float o[8];
+        {
+            const float4 b0 = *reinterpret_cast<const float4*>(pp + 10 * 8), b1 = *reinterpret_cast<const float4*>(pp + 10 * 8 + 4);
+            o[0] = b0.x; o[1] = b0.y; o[2] = b0.z; o[3] = b0.w;
+            o[4] = b1.x; o[5] = b1.y; o[6] = b1.z; o[7] = b1.w;
+        }
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const uint4 h0 = *reinterpret_cast<const uint4*>(pp + pr * 8), h1 = *reinterpret_cast<const uint4*>(pp + pr * 8 + 4);
+            const uint4 l0 = *reinterpret_cast<const uint4*>(pp + (5 + pr) * 8), l1 = *reinterpret_cast<const uint4*>(pp + (5 + pr) * 8 + 4);
+            const uint32_t wh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            const uint32_t wlo[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+            const v4i ra = raw[q][2 * pr], rb = raw[q][pr < 4 ? 2 * pr + 1 : 8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t ua = (uint32_t)ra[j], ub = (uint32_t)rb[j];
+                const uint32_t lo = pr < 4 ? __builtin_amdgcn_perm(ub, ua, 0x05040100u) : (ua & 0xffffu);
+                const uint32_t hi = pr < 4 ? __builtin_amdgcn_perm(ub, ua, 0x07060302u) : (ua >> 16);
+                // (the lo products first: they are 2^-11 of the hi ones)
+                o[2 * j] = Half16<HT>::dot2(lo, wh[2 * j], Half16<HT>::dot2(lo, wlo[2 * j], o[2 * j]));
+                o[2 * j + 1] = Half16<HT>::dot2(hi, wh[2 * j + 1], Half16<HT>::dot2(hi, wlo[2 * j + 1], o[2 * j + 1]));
+            }
+        }
+        float ol[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            o[i] = fmaxf(o[i], 0.f);
+            ol[i] = o[i] - (float)(HT)o[i];
+        }
+        const int row = r0 + q * 64;
+        const int sw = row * 128 + ((chunk ^ (row & 7)) << 4);
+        Vec8<HT>::store(reinterpret_cast<HT*>(lds + X_LDS_AH + (s & 1) * A_STAGE + sw), o);
+        Vec8<HT>::store(reinterpret_cast<HT*>(lds + X_LDS_AL + sw), ol);
+    };
+
+    // ---- prologue: taps and weights of slice 0 -> tiles(0), W hi(0) in LDS; then the taps of slice 1
+    load_taps(0, 0);
+    load_taps(0, 1);
+    load_w(0);
+    __syncthreads();                 // parameters of K-steps 0 .. 2 are in LDS
+    produce_a(0, 0);
+    produce_a(0, 1);
+    store_w(0);
+    if (nk > 1) { load_taps(1, 0); load_taps(1, 1); }
+
+    for (int s = 0; s < nk; ++s) {
+        const bool more = s + 1 < nk, more2 = s + 2 < nk;
+        // ---- j = 0: weight slice hi (ring slot 0) x hi tile (slot s & 1) and x lo tile
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own tile / weight / parameter writes are in LDS
+        __builtin_amdgcn_s_barrier();
+        load_w(2 * s + 1);
+        load_p(s + 3);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            v8 wa[4], ah[4], al[4];
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) wa[nj] = *reinterpret_cast<const v8*>(lds + w_off[nj] + (((kk * 4 + kq) ^ w_key[nj]) << 4));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                ah[mi] = *reinterpret_cast<const v8*>(lds + X_LDS_AH + (s & 1) * A_STAGE + a_off[mi] + (((kk * 4 + kq) ^ a_key[mi]) << 4));
+                al[mi] = *reinterpret_cast<const v8*>(lds + X_LDS_AL + a_off[mi] + (((kk * 4 + kq) ^ a_key[mi]) << 4));
+            }
+            // (the lo products first -- 2^-11 of the hi ones --, and the two products of one accumulator 16 MFMAs apart)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<HT>::mfma(wa[nj], al[mi], acc[mi][nj]);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<HT>::mfma(wa[nj], ah[mi], acc[mi][nj]);
+        }
+        store_w(2 * s + 1);
+        store_p(s + 3);
+        // ---- j = 1: weight slice lo (ring slot 1) x hi tile; the depthwise slice s + 1 -> the other hi slot, the lo tile
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (more) load_w(2 * s + 2);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            v8 wa[4], ah[4];
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) wa[nj] = *reinterpret_cast<const v8*>(lds + W_STAGE + w_off[nj] + (((kk * 4 + kq) ^ w_key[nj]) << 4));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                ah[mi] = *reinterpret_cast<const v8*>(lds + X_LDS_AH + (s & 1) * A_STAGE + a_off[mi] + (((kk * 4 + kq) ^ a_key[mi]) << 4));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<HT>::mfma(wa[nj], ah[mi], acc[mi][nj]);
+            if (more) {
+                produce_a(s + 1, kk);
+                if (more2) load_taps(s + 2, kk);
+            }
+        }
+        if (more) store_w(2 * s + 2);
+    }
+
+    // ---- epilogue: ReLU, split, store (bias was the accumulators' start value)
+    const int nbase = nt * TN + wn * 64 + kq * 16;
+    if (nbase + 16 <= p.N) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = mt * TM + wm * 64 + mi * 16 + fr;
+            if (m < p.M) {
+                float lo[8], hi[8];
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        lo[nj * 4 + r] = fmaxf(acc[mi][nj][r], 0.f);
+                        hi[nj * 4 + r] = fmaxf(acc[mi][2 + nj][r], 0.f);
+                    }
+                HT* cp = static_cast<HT*>(p.C) + (long long)m * p.ldc + nbase;
+                Vec8<HT>::store(cp, lo);
+                Vec8<HT>::store(cp + 8, hi);
+                if (p.C_lo) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { lo[i] -= (float)(HT)lo[i]; hi[i] -= (float)(HT)hi[i]; }
+                    HT* cl = static_cast<HT*>(p.C_lo) + (long long)m * p.ldc + nbase;
+                    Vec8<HT>::store(cl, lo);
+                    Vec8<HT>::store(cl + 8, hi);
+                }
+            }
+        }
+    }
+}
+
+int launch_dwpw_x(const DwPwArgs& a, hipStream_t s) {
+    constexpr int lds_bytes = X_LDS_P + XP_RING * XP_STEP;
+    static_assert(lds_bytes <= 160 * 1024, "k_dwpw_x LDS");
+    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw_x), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_dwpw_x, dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
 template <typename HT, int WSUB>
 int launch_dwpw_typed(const DwPwArgs& a, int mtiles, hipStream_t s) {
     const int lds_bytes = LDS_P + (a.K / 64) * P_STEP;
@@ -290,8 +533,9 @@ int launch_dwpw(const avl_seg_op& op, hipStream_t s) {
     const int mtiles = (a.M + TM - 1) / TM;
     a.mtiles = mtiles;
     a.per_xcd = (mtiles + 7) / 8;
-    a.order = reinterpret_cast<const int*>(a.dwp + (a.K / 64) * (P_STEP / 4));
+    a.order = reinterpret_cast<const int*>(a.dwp + (a.K / 64) * ((op.w_split == 2 ? XP_STEP : P_STEP) / 4));
     a.C_lo = op.out_lo;
+    if (op.w_split == 2) return launch_dwpw_x(a, s);         // exact depthwise stage: f16 weight pairs, split tile (pack_dw_pairs(split=True))
     if (op.w_split) return launch_dwpw_typed<f16, 2>(a, mtiles, s);
     return op.dtype == AVL_F16 ? launch_dwpw_typed<f16, 1>(a, mtiles, s) : launch_dwpw_typed<bf16, 1>(a, mtiles, s);
 }

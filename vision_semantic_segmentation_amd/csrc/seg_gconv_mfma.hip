@@ -374,8 +374,7 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
                         const auto r32 = __builtin_amdgcn_permlane32_swap(m16, m16, false, false);
                         amax = __uint_as_float(max(r32[0], r32[1]));
                     }
-                    const unsigned e = __float_as_uint(amax) >> 23;
-                    const unsigned sbyte = e >= 3u ? e - 2u : 1u;
+                    const unsigned sbyte = mx_fp4_scale_byte(amax);
                     const float scale = __uint_as_float(sbyte << 23);
                     unsigned pk = 0u;
                     pk = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pk, src[0], src[1], scale, 0);

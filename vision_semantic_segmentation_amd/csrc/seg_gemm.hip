@@ -602,8 +602,7 @@ __device__ __forceinline__ unsigned quantize_fp4_block(const float (&v)[16], uns
         const auto r16 = __builtin_amdgcn_permlane16_swap(ab, ab, false, false);
         amax = __uint_as_float(max(r16[0], r16[1]));
     }
-    const unsigned e = __float_as_uint(amax) >> 23;
-    const unsigned sbyte = e >= 3u ? e - 2u : 1u;            // 2^(floor(log2 amax) - 2): the block maximum lands in [4, 8) -> 4 or 6
+    const unsigned sbyte = mx_fp4_scale_byte(amax);
     const float scale = __uint_as_float(sbyte << 23);
     q[0] = q[1] = 0u;
 #define AVL_FP4_PAIR(i)                                                                                  \

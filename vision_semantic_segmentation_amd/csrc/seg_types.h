@@ -133,6 +133,16 @@ __device__ __forceinline__ void glds4_saddr(const void* sbase, unsigned voff, un
         : "memory");
 }
 
+// E8M0 scale byte of an MX-FP4 block whose largest magnitude is `amax` (>= 0): 2^(floor(log2 amax) - 2) puts the block maximum
+// into [4, 8), where e2m1 has the two values 4 and 6 and everything above 6 saturates; when the maximum would land above 6.5 the
+// scale is doubled instead (the maximum then rounds to 3.5 -> 4 rather than saturating to 6, at the price of a coarser grid for
+// the small elements of that block): -8 % rms logits error in tools/precision_study.py ("r3s", both weight seeds tried; 6.0 and
+// 7.0 as thresholds: about the same).  network.fp4_quant_blocks is the host twin, bit for bit.
+__device__ __forceinline__ unsigned mx_fp4_scale_byte(float amax) {
+    const unsigned ab = __float_as_uint(amax), e = ab >> 23;
+    return (e >= 3u ? e - 2u : 1u) + ((ab & 0x7fffffu) > 0x500000u ? 1u : 0u);          // mantissa > 1.625 <=> 4 m > 6.5
+}
+
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }

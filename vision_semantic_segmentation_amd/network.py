@@ -245,6 +245,27 @@ def pack_gconv_mx(w, groups):
     return frag_hi, torch.cat([w4.reshape(-1), w4s.reshape(-1)])
 
 
+def pack_dw_pairs_split(w, b):
+    """Depthwise parameters for k_dwpw_x (w_split = 2 of AVL_OP_DWPW): w float64 [C][1][3][3] and b [C] (BN folded) -> int32
+    [C/64][chunk 8][11][8]: five tap pairs of the f16 HI parts of the weights (tap 2p in the low half, tap 2p+1 in the high half; the
+    ninth tap pairs with zero), the same five pairs of the f16 LO parts (w - hi), and the fp32 bias bits."""
+    c = w.shape[0]
+    assert c % 64 == 0
+    w9 = w.reshape(c, 9).to(torch.float64)
+    hi, lo = split_f16(w9)
+
+    def pairs(part):
+        w16 = torch.cat([part, torch.zeros((c, 1), dtype=torch.float16)], dim=1)                      # [C][10]
+        bits = w16.view(torch.int16).to(torch.int32) & 0xFFFF
+        return (bits[:, 0::2] | (bits[:, 1::2] << 16)).reshape(c // 64, 8, 8, 5).permute(0, 1, 3, 2)   # [step][chunk][pair][ch]
+
+    out = torch.empty((c // 64, 8, 11, 8), dtype=torch.int32)
+    out[:, :, 0:5, :] = pairs(hi)
+    out[:, :, 5:10, :] = pairs(lo)
+    out[:, :, 10, :] = b.to(torch.float32).view(torch.int32).reshape(c // 64, 8, 8)
+    return out.reshape(-1)
+
+
 def pack_dw_pairs(w, b, act_dtype):
     """Depthwise parameters for the fused depthwise+pointwise kernel (AVL_OP_DWPW): w float64 [C][1][3][3] and b [C]
     (BN folded) -> int32 [C/64][chunk 8][6][8]: five tap pairs per channel (tap 2p in the low half, tap 2p+1 in the
@@ -303,12 +324,16 @@ _FP4_GRID = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0], dtype=torch.f
 
 def fp4_quant_blocks(b):
     """float64 [..., 32] -> (uint8 [..., 16], int64 [...]): one OCP MX-FP4 block per trailing 32 values: scale byte = biased
-    exponent of the block maximum - 2 (the maximum lands in [4, 8) and saturates to 6), e2m1 elements rounded to nearest even,
+    exponent of the block maximum - 2 (the maximum lands in [4, 8)), + 1 when it would land above 6.5; e2m1 elements rounded to nearest even,
     element 2i in the LOW nibble of byte i -- the convention of the GPU's v_cvt_scalef32_pk_fp4_f32 (tools/micro/fp4_cvt_probe.hip)."""
     b = b.to(torch.float64)
     amax = b.abs().amax(dim=-1)
     e = (torch.floor(torch.log2(amax.clamp_min(2.0 ** -200))).to(torch.int64) + 127).clamp_min(0)   # biased fp32 exponent of amax (0: zero / subnormal, as the GPU reads it)
-    sbyte = torch.where(e >= 3, e - 2, torch.ones_like(e)).clamp(1, 254)
+    sbyte = torch.where(e >= 3, e - 2, torch.ones_like(e))
+    # a block maximum above 6.5 (in units of that scale) takes the next scale instead of saturating at 6 (seg_types.h,
+    # mx_fp4_scale_byte: the test is on the float32 mantissa of the maximum, > 1.625)
+    mant = amax.to(torch.float32).view(torch.int32).to(torch.int64) & 0x7FFFFF
+    sbyte = (sbyte + (mant > 0x500000).to(torch.int64)).clamp(1, 254)
     scale = torch.exp2((sbyte - 127).to(torch.float64)).unsqueeze(-1)
     mag = (b.abs() / scale).clamp_max(6.0)
     mid = (_FP4_GRID[1:] + _FP4_GRID[:-1]) / 2
@@ -386,7 +411,7 @@ class SegNet(object):
     native plan.  ``forward(image_u8_cuda)`` runs it; ``labels`` / ``logits`` are views of its outputs."""
 
     ROW_PAD = 256        # GEMM tiles read whole 128/256-row tiles
-    MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx")    # keyword switches of the "mixed" mode
+    MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx", "dw_exact")    # keyword switches of the "mixed" mode
 
     def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8, fuse_dwpw=True, **mixed_opts):
         assert output_stride == 8, "the reference configuration is OS8 (base_cfg.py:106)"
@@ -407,7 +432,8 @@ class SegNet(object):
         self.mixed_mx = self.mixed and mixed_opts.get("mx", True)
         self.mixed_trunk_fp4 = mixed_opts.get("trunk_fp4", True)
         self.mixed_fuse_ds = mixed_opts.get("fuse_ds", True)     # stride-1 downsample folded into conv3 (second input along K)
-        self.mixed_gconv_mx = mixed_opts.get("gconv_mx", False)  # grouped conv with FP4 corrections for its weights AND for conv1's output (-12 % logits error, -5 % frames/s)
+        self.mixed_dw_exact = mixed_opts.get("dw_exact", True)    # fused depthwise+pointwise (ASPP) with split depthwise weights and a split depthwise result (k_dwpw_x)
+        self.mixed_gconv_mx = mixed_opts.get("gconv_mx", True)   # grouped conv with FP4 corrections for its weights AND for conv1's output (-10..-30 % logits error, -5 % frames/s)
         self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "mixed": torch.float16}[precision]
         self.avl_dtype = {"bf16": _lib.AVL_BF16, "f16": _lib.AVL_F16, "f32": _lib.AVL_F32, "mixed": _lib.AVL_F16}[precision]
         self.half = precision != "f32"              # 16-bit activations: MFMA stem / grouped-conv kernels
@@ -563,13 +589,15 @@ class SegNet(object):
         bp[:cout] = b_pw
         wdev = self._dev(pack_split_rows(wp, 2), torch.float16) if self.mixed else self._dev(wp, self.act_dtype)
         bdev = self._dev(bp, torch.float32)
-        params = torch.cat([pack_dw_pairs(w_dw, b_dw, self.act_dtype), dwpw_tile_order(oh, ow, dilation)]).to(self.device)
+        exact = self.mixed and self.mixed_dw_exact
+        dwp = pack_dw_pairs_split(w_dw, b_dw) if exact else pack_dw_pairs(w_dw, b_dw, self.act_dtype)
+        params = torch.cat([dwp, dwpw_tile_order(oh, ow, dilation)]).to(self.device)
         self._keep.append(params)
         ip, ild, irows = self._view(src)
         op_, old, orows = self._view(dst, dst_col)
         self._op(name, OP_DWPW, in_=ip, in2=params.data_ptr(), out=op_, weight=wdev.data_ptr(), bias=bdev.data_ptr(), in_h=h, in_w=wd,
                  in_c=cin, in_ld=ild, in_rows=irows, out_h=oh, out_w=ow, out_c=cout, out_ld=old, out_rows=orows, relu=1, w_rows=w_rows,
-                 ksize=3, stride=1, pad=padding, dil=dilation, groups=cin, w_split=int(self.mixed),
+                 ksize=3, stride=1, pad=padding, dil=dilation, groups=cin, w_split=(2 if exact else int(self.mixed)),
                  out_lo=self._lo(dst, dst_col) if self.mixed else 0)
 
     def _spatial(self, name, kind, src, in_hw, cin, dst, out_hw, cout, weight=None, bias=None, dst_col=0, **extra):

@@ -47,7 +47,7 @@ class SemanticSegmentation(object):
         if key not in self._nets:
             net = SegNet(self.state, key[0], key[1], precision=self.precision, device=self.device, num_classes=self.num_classes,
                          conv2_split=bool(getattr(self.cfg.MODEL, "MIXED_CONV2_SPLIT", True)),
-                         gconv_mx=bool(getattr(self.cfg.MODEL, "MIXED_GCONV_MX", False)),
+                         gconv_mx=bool(getattr(self.cfg.MODEL, "MIXED_GCONV_MX", True)),
                          trunk_fp4=bool(getattr(self.cfg.MODEL, "MIXED_TRUNK_FP4", True)))
             if getattr(self.cfg.MODEL, "HIP_GRAPH", True):
                 net.capture_graph()
