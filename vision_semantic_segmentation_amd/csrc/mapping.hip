@@ -314,34 +314,6 @@ __device__ __forceinline__ void cast_vote_byte_lists(unsigned* cell_mask, int* t
     if (first && slot < cap) touched[(long long)list * cap + slot] = cell;
 }
 
-// One point of the fused frame: project (:367-383), fetch its label (RGB match or class LUT through the INTER_NEAREST source
-// index), cell from the ORIGINAL coordinates (:404-411), lane bonus -> (cell, vote); cell = -1 / vote = 0 when it does not count.
-template <int SRC>
-__device__ __forceinline__ void point_vote(int k, const PtsView& pv, const ProjParams& pp, const GridParams& g,
-                                           const unsigned char* __restrict__ src, int src_w, int src_h, const LutParams& lut,
-                                           int& cell, unsigned& vote) {
-    cell = -1;
-    vote = 0;
-    if (k >= pv.n) return;
-    double x, y, z, it;
-    load_point(pv, k, x, y, z, it);
-    int ix, iy;
-    if (!project(pp, x, y, z, ix, iy)) return;
-    cell = grid_cell(g, x, y, z);
-    if (cell < 0) return;
-    if (SRC == AVL_SRC_RGB) {
-        const unsigned char* px = src + 3ll * ((long long)iy * src_w + ix);
-        vote = vote_from_rg(g, px[0], px[1]);
-    } else {
-        // cv2 INTER_NEAREST source index: min(floor(d * (src/dst)), src - 1), double arithmetic
-        int sx = ix, sy = iy;
-        if (src_w != pp.img_w) sx = min((int)__builtin_floor((double)ix * ((double)src_w / (double)pp.img_w)), src_w - 1);
-        if (src_h != pp.img_h) sy = min((int)__builtin_floor((double)iy * ((double)src_h / (double)pp.img_h)), src_h - 1);
-        vote = lut.lut[src[(long long)sy * src_w + sx]];
-    }
-    vote = add_bonus(vote, g.bonus_classes, it);
-}
-
 // MODE: 0 = 32-bit mask + touched list, 1 = 32-bit mask only (sweep), 2 = byte mask only (sweep, see encode_vote_byte),
 //       3 = byte mask + partitioned touched lists (k_grid_apply_lists)
 template <int SRC, int MODE>
@@ -352,7 +324,27 @@ __global__ void __launch_bounds__(kBlock) k_fused_vote(PtsView pv, ProjParams pp
     const int k = blockIdx.x * kBlock + threadIdx.x;
     int cell = -1;
     unsigned vote = 0;
-    point_vote<SRC>(k, pv, pp, g, src, src_w, src_h, lut, cell, vote);
+    if (k < pv.n) {
+        double x, y, z, it;
+        load_point(pv, k, x, y, z, it);
+        int ix, iy;
+        if (project(pp, x, y, z, ix, iy)) {
+            cell = grid_cell(g, x, y, z);
+            if (cell >= 0) {
+                if (SRC == AVL_SRC_RGB) {
+                    const unsigned char* px = src + 3ll * ((long long)iy * src_w + ix);
+                    vote = vote_from_rg(g, px[0], px[1]);
+                } else {
+                    // cv2 INTER_NEAREST source index: min(floor(d * (src/dst)), src - 1), double arithmetic
+                    int sx = ix, sy = iy;
+                    if (src_w != pp.img_w) sx = min((int)__builtin_floor((double)ix * ((double)src_w / (double)pp.img_w)), src_w - 1);
+                    if (src_h != pp.img_h) sy = min((int)__builtin_floor((double)iy * ((double)src_h / (double)pp.img_h)), src_h - 1);
+                    vote = lut.lut[src[(long long)sy * src_w + sx]];
+                }
+                vote = add_bonus(vote, g.bonus_classes, it);
+            }
+        }
+    }
     if (MODE == 0) cast_vote(cell_mask, touched, counter, cell, vote);
     else if (MODE == 1) cast_vote_nolist(cell_mask, cell, vote);
     else if (MODE == 2) cast_vote_byte(cell_mask, cell, vote, g.C, g.bonus_classes);
@@ -547,217 +539,6 @@ __global__ void __launch_bounds__(kBlock) k_grid_sweep_bytes(MapT* __restrict__ 
             const unsigned e = list[k];
             const unsigned m = e & 0xffu;
             MapT* row = map + (base + (e >> 8)) * C;
-            double vals[AVL_MAX_MAP_CLASSES];
-#pragma unroll
-            for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
-                if (c < C) vals[c] = (double)row[c];
-            int r = 0;
-            for (int i = 0; i < C; ++i) {
-                if (m & (1u << i)) {
-#pragma unroll
-                    for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
-                        if (c < C) vals[c] = (double)(MapT)(vals[c] + cm.cm[c * C + i]);
-                }
-                if ((bonus_classes >> i) & 1u) {
-                    if (m & (1u << (C + r))) {
-#pragma unroll
-                        for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
-                            if (c == i) vals[c] = (double)(MapT)(vals[c] + 2.0);
-                    }
-                    ++r;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
-                if (c < C) row[c] = (MapT)vals[c];
-        }
-        __syncthreads();
-    }
-}
-
-// ================================================================ binned votes (MODE 4 of avl_fused_frame, round 3)
-// Dense clouds were bound by two things the cloud does not need: one scattered GLOBAL atomicOr per point (1 M of them: 16-18 us
-// whatever the kernel around them does) and a sweep of the whole 16 MB byte mask (config E: 44 us per frame, 2.15 x the
-// algorithmic bytes).  Here the vote aggregation happens in LDS and there is no global mask at all:
-//   k_bin_points   a workgroup of 1024 lanes takes P = 1024 x PPT consecutive points, computes (cell, vote byte) for each, and
-//                  sorts its records by GRID TILE (kTile = 16384 consecutive cells) in LDS: histogram by LDS atomics (the returned
-//                  rank is the record's place inside its tile's run), exclusive scan, scatter into an LDS staging array, one
-//                  coalesced copy to the workgroup's own segment of the record buffer; table[wg][tile] = start << 16 | count.
-//                  No global atomic, no overflow case: a segment has exactly P slots.
-//   k_tile_apply   one workgroup per tile: gathers the tile's runs from every producer segment (a 256-lane scan of the counts,
-//                  then lanes stride over the flattened records), ORs the vote bytes into a 16 KB LDS mask (idempotent: any order
-//                  gives the same mask), and applies the non-zero cells to the grid rows exactly as k_grid_sweep_bytes does
-//                  (class order of the reference, lane bonus after its class: float64 grids stay bit-identical to NumPy's).
-// Algorithmic traffic: 16 n (points) + 1 n (labels, L2) + 8 n (records out and in) + table + 2 C 8 U (rows).
-constexpr int kTileShift = 14, kTile = 1 << kTileShift;         // cells per grid tile
-constexpr int kBinThreads = 1024;
-constexpr int kMaxTiles = 2048;                                  // LDS histogram of k_bin_points
-constexpr int kApplyChunk = 4096;                                // cells listed per round of k_tile_apply
-
-template <int SRC, int PPT>
-__global__ void __launch_bounds__(kBinThreads) k_bin_points(PtsView pv, ProjParams pp, GridParams g, const unsigned char* __restrict__ src,
-                                                            int src_w, int src_h, LutParams lut, int ntiles,
-                                                            unsigned* __restrict__ records, unsigned* __restrict__ table) {
-    __shared__ unsigned hist[kMaxTiles];          // count per tile, then the tile's start inside the segment
-    __shared__ unsigned stage[kBinThreads * PPT];
-    __shared__ unsigned wave_sum[kBinThreads / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int P = kBinThreads * PPT;
-    for (int i = tid; i < ntiles; i += kBinThreads) hist[i] = 0u;
-    __syncthreads();
-    unsigned rec[PPT], rank[PPT];
-    int tile[PPT];
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        const int k = blockIdx.x * P + i * kBinThreads + tid;
-        int cell;
-        unsigned vote;
-        point_vote<SRC>(k, pv, pp, g, src, src_w, src_h, lut, cell, vote);
-        tile[i] = -1;
-        rec[i] = 0u;
-        rank[i] = 0u;
-        if (cell >= 0 && vote != 0u) {
-            tile[i] = cell >> kTileShift;
-            rec[i] = ((unsigned)(cell & (kTile - 1)) << 8) | encode_vote_byte(vote, g.C, g.bonus_classes);
-            rank[i] = atomicAdd(&hist[tile[i]], 1u);
-        }
-    }
-    __syncthreads();
-    // exclusive scan of hist[0 .. ntiles): every lane owns 2 consecutive tiles (kMaxTiles = 2 x 1024)
-    const unsigned c0 = 2 * tid < ntiles ? hist[2 * tid] : 0u, c1 = 2 * tid + 1 < ntiles ? hist[2 * tid + 1] : 0u;
-    unsigned incl = c0 + c1;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned up = __shfl_up(incl, off);
-        if (lane >= off) incl += up;
-    }
-    if (lane == 63) wave_sum[wave] = incl;
-    __syncthreads();
-    unsigned base = 0u;
-    for (int w = 0; w < wave; ++w) base += wave_sum[w];
-    const unsigned s0 = base + incl - (c0 + c1), s1 = s0 + c0;
-    unsigned* trow = table + (long long)blockIdx.x * ntiles;
-    if (2 * tid < ntiles) { hist[2 * tid] = s0; trow[2 * tid] = (s0 << 16) | c0; }
-    if (2 * tid + 1 < ntiles) { hist[2 * tid + 1] = s1; trow[2 * tid + 1] = (s1 << 16) | c1; }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PPT; ++i)
-        if (tile[i] >= 0) stage[hist[tile[i]] + rank[i]] = rec[i];
-    __syncthreads();
-    unsigned total = 0u;
-    for (int w = 0; w < kBinThreads / 64; ++w) total += wave_sum[w];
-    unsigned* seg = records + (long long)blockIdx.x * P;
-    for (unsigned i = tid; i < total; i += kBinThreads) seg[i] = stage[i];
-}
-
-template <typename MapT>
-__global__ void __launch_bounds__(kBlock) k_tile_apply(MapT* __restrict__ map, int C, unsigned bonus_classes, CmParams cm, long long ncell,
-                                                       int ntiles, int nprod, int seg_len, const unsigned* __restrict__ records,
-                                                       const unsigned* __restrict__ table) {
-    __shared__ unsigned mask32[kTile / 4];
-    __shared__ unsigned list[kApplyChunk];
-    __shared__ unsigned pbase[1024 + 1], pstart[1024];
-    __shared__ unsigned wsum[kBlock / 64];
-    __shared__ int count;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = blockIdx.x;
-    for (int i = tid; i < kTile / 4; i += kBlock) mask32[i] = 0u;
-    // ---- the tile's runs: producers in groups of 1024 (a 1 M-point cloud has 245)
-    for (int p0 = 0; p0 < nprod; p0 += 1024) {
-        const int np = min(1024, nprod - p0);
-        __syncthreads();                                         // (mask zeroed / the previous group's gather is complete)
-        // exclusive scan of the counts of producers p0 .. p0 + np: every lane owns 4 consecutive producers
-        unsigned c[4], sum = 0u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pidx = 4 * tid + i;
-            unsigned e = 0u;
-            if (pidx < np) e = table[(long long)(p0 + pidx) * ntiles + t];
-            c[i] = e & 0xffffu;
-            if (pidx < np) pstart[pidx] = e >> 16;
-            sum += c[i];
-        }
-        unsigned incl = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned up = __shfl_up(incl, off);
-            if (lane >= off) incl += up;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        unsigned base = 0u;
-        for (int w = 0; w < wave; ++w) base += wsum[w];
-        unsigned run = base + incl - sum;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (4 * tid + i < np) pbase[4 * tid + i] = run;
-            run += c[i];
-        }
-        unsigned total = 0u;
-        for (int w = 0; w < kBlock / 64; ++w) total += wsum[w];
-        if (tid == 0) pbase[np] = total;
-        __syncthreads();
-        // lanes stride over the flattened records; producer of record j = the last p with pbase[p] <= j (binary search in LDS)
-        for (unsigned j = tid; j < total; j += kBlock) {
-            int lo = 0, hi = np - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (pbase[mid] <= j) lo = mid; else hi = mid - 1;
-            }
-            const unsigned r = records[(long long)(p0 + lo) * seg_len + pstart[lo] + (j - pbase[lo])];
-            const unsigned local = r >> 8;
-            atomicOr(&mask32[local >> 2], (r & 0xffu) << (8u * (local & 3u)));
-        }
-    }
-    __syncthreads();
-    // ---- non-zero cells -> rows, kApplyChunk cells at a time: every lane inspects 16 mask bytes, the non-zero ones are listed in
-    // LDS (lane counts -> wave scan -> one LDS atomic per wave), then ALL lanes apply one listed cell each
-    const long long cell0 = (long long)t << kTileShift;
-    for (int ch = 0; ch < kTile / kApplyChunk; ++ch) {
-        if (tid == 0) count = 0;
-        __syncthreads();
-        const uint4 v = *reinterpret_cast<const uint4*>(&mask32[(ch * kApplyChunk + tid * 16) / 4]);
-        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
-        int mine = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned tt = w4[q] | (w4[q] >> 4);
-            tt |= tt >> 2;
-            tt |= tt >> 1;
-            mine += __builtin_popcount(tt & 0x01010101u);
-        }
-        int incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(incl, off);
-            if (lane >= off) incl += up;
-        }
-        int wave_base = 0;
-        if (lane == 63 && incl > 0) wave_base = atomicAdd(&count, incl);
-        wave_base = __shfl(wave_base, 63);
-        int slot = wave_base + incl - mine;
-        if (mine > 0) {
-            const int local0 = ch * kApplyChunk + tid * 16;
-            auto take = [&](unsigned x, int first) {
-                while (x) {
-                    const int b = __builtin_ctz(x) >> 3;
-                    list[slot++] = ((unsigned)(local0 + first + b) << 8) | ((x >> (8 * b)) & 0xffu);
-                    x &= ~(0xffu << (8 * b));
-                }
-            };
-            take(v.x, 0);
-            take(v.y, 4);
-            take(v.z, 8);
-            take(v.w, 12);
-        }
-        __syncthreads();
-        const int n = count;
-        for (int k = tid; k < n; k += kBlock) {
-            const unsigned e = list[k];
-            const unsigned m = e & 0xffu;
-            const long long cell = cell0 + (e >> 8);
-            if (cell >= ncell) continue;
-            MapT* row = map + cell * C;
             double vals[AVL_MAX_MAP_CLASSES];
 #pragma unroll
             for (int c = 0; c < AVL_MAX_MAP_CLASSES; ++c)
@@ -1017,29 +798,6 @@ int launch_apply_lists(const avl_grid* g, const double* cm_host, unsigned bonus,
     return AVL_OK;
 }
 
-// binned votes (MODE 4): geometry shared by the two launches.  Points per producer workgroup: 4096 for big clouds, 1024 otherwise
-// (more workgroups); the record segments and the [producer][tile] table live in g->touched.
-struct BinGeom { int ppt, P, nprod, ntiles; long long need; };
-BinGeom bin_geom(const avl_grid* g, int n) {
-    BinGeom b;
-    b.ppt = n >= (1 << 18) ? 4 : 1;
-    b.P = kBinThreads * b.ppt;
-    b.nprod = (n + b.P - 1) / b.P;
-    b.ntiles = (int)(((long long)g->Hm * g->Wm + kTile - 1) >> kTileShift);
-    b.need = (long long)b.nprod * b.P + (long long)b.nprod * b.ntiles;
-    return b;
-}
-// Measured (tools/bench_mapping.py): config E (1 M points, 16 M cells) and config C (120 k points, 4 M cells) -- see DESIGN 3.1.
-// AVL_APPLY_MODE=bin forces it where it is possible, any other value of AVL_APPLY_MODE disables it (experiments).
-bool use_bins(const avl_grid* g, int n, unsigned bonus) {
-    static const char* mode = getenv("AVL_APPLY_MODE");
-    if (g->C + __builtin_popcount(bonus) > 8) return false;
-    const BinGeom b = bin_geom(g, n);
-    if (b.ntiles > kMaxTiles || b.need > g->touched_cap) return false;
-    if (mode) return mode[0] == 'b';
-    return n >= 32768;
-}
-
 // list (sparse) vs sweep (dense) apply: the sweep reads Hm*Wm*4 bytes whatever the cloud; the list costs a
 // returning atomic + an append per first touch.  AVL_APPLY_MODE=list|scan overrides (experiments).
 bool use_scan(const avl_grid* g, int n, unsigned bonus) {
@@ -1170,29 +928,6 @@ extern "C" int avl_fused_frame(const avl_grid* g, const void* pts, int n, int dt
     AVL_REQUIRE(g->touched_cap >= (n < g->Hm * g->Wm ? n : g->Hm * g->Wm), "touched_cap %d too small", g->touched_cap);
     hipStream_t s = avl::as_stream(stream);
     const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
-    if (use_bins(g, n, bonus_classes)) {
-        const BinGeom bg = bin_geom(g, n);
-        unsigned* records = reinterpret_cast<unsigned*>(g->touched);
-        unsigned* table = records + (long long)bg.nprod * bg.P;
-        CmParams cm;
-        memset(&cm, 0, sizeof(cm));
-        AVL_REQUIRE(cm_host, "cm_host is NULL");
-        memcpy(cm.cm, cm_host, sizeof(double) * g->C * g->C);
-#define AVL_BIN(SRC, PPT) hipLaunchKernelGGL((k_bin_points<SRC, PPT>), dim3(bg.nprod), dim3(kBinThreads), 0, s, pv, pp, gp, src, src_w, src_h, lut, bg.ntiles, records, table)
-        if (src_kind == AVL_SRC_RGB) { if (bg.ppt == 4) AVL_BIN(AVL_SRC_RGB, 4); else AVL_BIN(AVL_SRC_RGB, 1); }
-        else { if (bg.ppt == 4) AVL_BIN(AVL_SRC_CLASSMAP, 4); else AVL_BIN(AVL_SRC_CLASSMAP, 1); }
-#undef AVL_BIN
-        AVL_LAUNCH_CHECK();
-        const long long ncell = (long long)g->Hm * g->Wm;
-        if (g->map_dtype == AVL_F64)
-            hipLaunchKernelGGL(k_tile_apply<double>, dim3(bg.ntiles), dim3(kBlock), 0, s, static_cast<double*>(g->map), g->C, bonus_classes, cm, ncell,
-                               bg.ntiles, bg.nprod, bg.P, records, table);
-        else
-            hipLaunchKernelGGL(k_tile_apply<float>, dim3(bg.ntiles), dim3(kBlock), 0, s, static_cast<float*>(g->map), g->C, bonus_classes, cm, ncell,
-                               bg.ntiles, bg.nprod, bg.P, records, table);
-        AVL_LAUNCH_CHECK();
-        return AVL_OK;
-    }
     const bool scan = use_scan(g, n, bonus_classes);
     const int mode = use_lists(g, n, bonus_classes) ? 3 : !scan ? 0 : (byte_mask_ok(g, bonus_classes) ? 2 : 1);
     if (mode == 0) AVL_HIP_CHECK(hipMemsetAsync(g->counter, 0, 16, s));      // only the single touched-list path counts there

@@ -80,9 +80,6 @@ class DeviceGrid(object):
 
     def ensure_capacity(self, n):
         need = min(int(n), self.Hm * self.Wm) + 64 * 256      # + the rounding slack of the partitioned lists (mapping.hip, kLists)
-        # binned votes (mapping.hip, bin_geom): one record slot per point (segments of 1024 or 4096) + the [producer][tile] table
-        ntiles = (self.Hm * self.Wm + 16383) // 16384
-        need = max(need, int(n) + 4096 + ((int(n) + 1023) // 1024) * ntiles)
         if need > self.touched_cap:
             self.touched_cap = max(need, 2 * self.touched_cap)
             self.touched = torch.empty(self.touched_cap, dtype=torch.int32, device=self.device)
