@@ -146,6 +146,17 @@ int avl_colorize_labels(const uint8_t* labels, int lw, int lh, const uint8_t* pa
 int avl_preprocess_image(const uint8_t* bgr, int h, int w, const double* K_host, const double* dist_host, int factor,
                          uint8_t* rgb_out, void* stream);
 
+/* The same pre-processing INSIDE the network's first kernel: an AVL_OP_STEM op whose `in2` is set reads the RAW BGR camera
+ * frame through `in` and applies BGR->RGB / undistort / INTER_AREA per pixel while it fills its LDS tile (the function
+ * avl_preprocess_image applies, so the results are the same bytes), i.e. the RGB network input is never written or re-read.
+ * Geometry of such an op: in_h x in_w = the NETWORK input (what avl_preprocess_image would have produced), in2_ld = src_w,
+ * in_rows = src_h * src_w of the raw frame; the integer factor is src_w / in_w (in_h == src_h / factor is checked).
+ * `in2` points at AVL_STEM_CAMERA_BYTES of DEVICE memory holding the camera model, written by avl_stem_camera_set()
+ * (stream-ordered: a plan captured into a hipGraph serves camera1 and camera6 alike; K_host / dist_host as above, both NULL
+ * = no undistortion). */
+#define AVL_STEM_CAMERA_BYTES 64
+int avl_stem_camera_set(void* camera_dev, const double* K_host, const double* dist_host, void* stream);
+
 /* ---- the semantic point cloud mapping() publishes (src/mapping.py:316-317) ---------------
  * create_point_cloud (src/utils/utils_ros.py:31-59) without its per-point struct.pack loop: record k (16 bytes,
  * point_step 16) = float32 x,y,z of pcd[0:3][k] and uint32 rgba = r | g<<8 | b<<16 | 255<<24 of label[:,k].
@@ -231,7 +242,8 @@ typedef struct avl_seg_op {
     int32_t dtype;           /* activation type of in/in2/out: AVL_BF16, AVL_F16 or AVL_F32      */
     const void* in;          /* input activation (STEM: uint8 image; GEMV/GAP-out: fp32)       */
     const void* in2;         /* GEMM: residual added before the ReLU, or NULL; GAP: fp32 scratch [256][C];
-                                DWCONV: 32 zero bytes (what a tap outside the image reads)          */
+                                DWCONV: 32 zero bytes (what a tap outside the image reads);
+                                STEM: NULL, or the camera block of a pre-processing stem (avl_stem_camera_set) */
     void* out;
     const void* weight;      /* packed by the host, layout per kind (see network.py)            */
     const float* bias;       /* fp32 [out_c padded], or NULL                                    */

@@ -226,6 +226,55 @@ def test_preprocessing_matches_restatement(cuda_device):
     assert np.abs(got - ref).max() <= 1
 
 
+def test_stem_preprocesses_the_raw_camera_frame(state, cuda_device):
+    """SURVEY 8f row 1 fused: a raw_frame plan's stem applies the pre-processing in its loader.  Its logits must be the SAME BITS as
+    avl_preprocess_image -> the plain plan (one shared device function), at the camera's 1440x1920 with camera1's distortion model,
+    with the 0.5 scale of the reference's example.yaml, with a factor that leaves a remainder, and after switching cameras on a
+    captured plan.  Prints the stem's time with and without the fused pre-processing next to the stand-alone kernel's."""
+    import torch
+    from vision_semantic_segmentation_amd import SemanticSegmentation
+    from vision_semantic_segmentation_amd.camera import camera_setup_1, camera_setup_6
+    from vision_semantic_segmentation_amd.vision_semantic_segmentation_node import preprocess_device
+    rng = np.random.default_rng(21)
+    cam1, cam6 = camera_setup_1(), camera_setup_6()
+    seg = SemanticSegmentation(_cfg("mixed"), device=cuda_device, state_dict=state)
+
+    def both(bgr, cam, factor):
+        rgb = preprocess_device(bgr, cam, factor)
+        want = seg.logits(rgb).clone()
+        got_labels = seg.segmentation_device_raw(bgr, None if cam is None else cam.K, None if cam is None else cam.dist, factor)
+        net = seg.net_for(rgb.shape[0], rgb.shape[1], raw_frame=bgr.shape[:2])
+        assert torch.equal(net.logits.permute(2, 0, 1), want), (bgr.shape, factor)
+        assert torch.equal(got_labels, want.argmax(0).to(torch.uint8))
+        return net
+
+    coarse = rng.integers(0, 256, size=(45, 60, 3), dtype=np.uint8)
+    bgr = np.repeat(np.repeat(coarse, 32, axis=0), 32, axis=1)                  # 1440 x 1920 with structure
+    bgr = (bgr.astype(np.int32) + rng.integers(-8, 9, size=bgr.shape)).clip(0, 255).astype(np.uint8)
+    net = both(bgr, cam1, 1)
+    both(bgr, cam6, 1)                                                          # same captured plan, other camera block
+    both(bgr, None, 1)
+    stem_fused = [r["ms"] for r in net.profile() if r["kind"] == "stem"][0]
+    stem_plain = [r["ms"] for r in seg.net_for(1440, 1920).profile() if r["kind"] == "stem"][0]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    t = torch.from_numpy(bgr).cuda()
+    preprocess_device(t, cam1, 1)
+    ev[0].record()
+    for _ in range(10):
+        preprocess_device(t, cam1, 1)
+    ev[1].record()
+    torch.cuda.synchronize()
+    print("1440x1920, camera1 undistortion: stand-alone k_preprocess %.3f ms + stem %.3f ms  vs  pre-processing stem %.3f ms"
+          % (ev[0].elapsed_time(ev[1]) / 10, stem_plain, stem_fused))
+    del net
+    seg._nets.clear()
+    torch.cuda.empty_cache()
+    both(bgr, cam1, 2)                                                          # IMAGE_SCALE 0.5 -> 720 x 960
+    small = rng.integers(0, 256, size=(487, 645, 3), dtype=np.uint8)            # 487 x 645 / 3 -> 162 x 215: remainder rows and columns
+    both(small, cam1, 3)
+    both(small, None, 2)
+
+
 def test_node_with_ros_style_messages_and_two_camera_threads(state, cuda_device):
     """The use_ros path of VisionSemanticSegmentationNode without ROS: a sensor_msgs/Image-like message (bytes payload with
     row padding, height / width / step / encoding) is decoded, the colour image is published as an 8UC3 Image carrying the

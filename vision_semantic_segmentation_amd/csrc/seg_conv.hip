@@ -5,6 +5,7 @@
 // on purpose: the address is wave-uniform, so hipcc fetches them through the scalar cache and the
 // inner loops are pure v_fmac with an SGPR operand.
 #include "seg_types.h"
+#include "seg_preprocess.h"
 
 namespace avl {
 namespace {
@@ -529,64 +530,16 @@ __global__ void __launch_bounds__(kThreads) k_subsample(const T* __restrict__ in
 }
 
 // ---------------------------------------------------------------------------------- pre-processing
-// vision_semantic_segmentation_node.py:83-98 fused: BGR->RGB, cv2.undistort (plumb-bob remap, bilinear, zero border),
-// INTER_AREA downscale by an integer factor.  One lane = one output pixel.  Undistortion happens at full resolution
-// (as in the reference) by sampling the f x f box of undistorted pixels on the fly.
-struct PreParams {
-    float fx, fy, cx, cy, k1, k2, p1, p2, k3;
-    int undistort, factor;
-};
-
-__device__ __forceinline__ void undistorted_rgb(const unsigned char* __restrict__ bgr, int H, int W, const PreParams& q, int u, int v,
-                                                int (&rgb)[3]) {
-    if (!q.undistort) {
-        const unsigned char* p = bgr + 3ll * ((long long)v * W + u);
-        rgb[0] = p[2]; rgb[1] = p[1]; rgb[2] = p[0];
-        return;
-    }
-    const double x = ((double)u - q.cx) / q.fx, y = ((double)v - q.cy) / q.fy;
-    const double r2 = x * x + y * y;
-    const double radial = 1.0 + q.k1 * r2 + q.k2 * r2 * r2 + q.k3 * r2 * r2 * r2;
-    const double xd = x * radial + 2.0 * q.p1 * x * y + q.p2 * (r2 + 2.0 * x * x);
-    const double yd = y * radial + q.p1 * (r2 + 2.0 * y * y) + 2.0 * q.p2 * x * y;
-    const float sx = (float)(q.fx * xd + q.cx), sy = (float)(q.fy * yd + q.cy);
-    const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
-    const float ax = sx - (float)x0, ay = sy - (float)y0;
-    float acc[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            const int xx = x0 + dx, yy = y0 + dy;
-            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-            const float wgt = (dx ? ax : 1.f - ax) * (dy ? ay : 1.f - ay);
-            const unsigned char* p = bgr + 3ll * ((long long)yy * W + xx);
-            acc[0] += wgt * (float)p[2]; acc[1] += wgt * (float)p[1]; acc[2] += wgt * (float)p[0];
-        }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) rgb[c] = min(max(__float2int_rn(acc[c]), 0), 255);
-}
-
+// vision_semantic_segmentation_node.py:83-98 as a stand-alone kernel (seg_preprocess.h); one lane = one output pixel.
+// The network path does not use it: the stem's loader applies the same function while it fills its LDS tile.
 __global__ void __launch_bounds__(kThreads) k_preprocess(const unsigned char* __restrict__ bgr, int H, int W, PreParams q,
                                                         unsigned char* __restrict__ out, int OH, int OW) {
     const int idx = blockIdx.x * kThreads + threadIdx.x;
     if (idx >= OH * OW) return;
-    const int oy = idx / OW, ox = idx % OW, f = q.factor;
-    int sum[3] = {0, 0, 0};
-    for (int dy = 0; dy < f; ++dy)
-        for (int dx = 0; dx < f; ++dx) {
-            int rgb[3];
-            undistorted_rgb(bgr, H, W, q, ox * f + dx, oy * f + dy, rgb);
-            sum[0] += rgb[0]; sum[1] += rgb[1]; sum[2] += rgb[2];
-        }
+    int v[3];
+    preprocessed_rgb(bgr, H, W, q.cam, q.factor, idx % OW, idx / OW, v);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        int v;
-        if (f == 1) v = sum[c];
-        else if (f == 2) v = (sum[c] + 2) >> 2;                                   // OpenCV's integer 2x2 path
-        else v = min(max(__float2int_rn((float)sum[c] * (1.0f / (float)(f * f))), 0), 255);
-        out[3ll * idx + c] = (unsigned char)v;
-    }
+    for (int c = 0; c < 3; ++c) out[3ll * idx + c] = (unsigned char)v[c];
 }
 
 inline unsigned blocks_for(long long n) { return (unsigned)((n + kThreads - 1) / kThreads); }
@@ -715,6 +668,16 @@ int validate_conv_op(const avl_seg_op& op) {
             AVL_REQUIRE(op.out_h == (op.in_h + 6 - 7) / 2 + 1 && op.out_w == (op.in_w + 6 - 7) / 2 + 1, "stem output size");
             AVL_REQUIRE(op.out_rows >= out_pix && op.out_ld >= 64 && (op.out_ld * es) % 16 == 0, "stem output buffer");
             AVL_REQUIRE(op.w_layout == 0 || (op.w_layout == 1 && is_half(op.dtype)), "stem weight layout %d", op.w_layout);
+            if (op.in2) {      // pre-processing in the loader: `in` is the raw BGR frame [in_rows / in2_ld][in2_ld][3], in2 the camera block
+                AVL_REQUIRE(op.w_layout == 1, "the pre-processing stem is the MFMA kernel (w_layout 1)");
+                AVL_REQUIRE(reinterpret_cast<uintptr_t>(op.in2) % 4 == 0, "stem camera block alignment");
+                AVL_REQUIRE(op.in2_ld > 0 && op.in_rows > 0 && op.in_rows % op.in2_ld == 0, "stem raw frame: in_rows = src_h * src_w, in2_ld = src_w");
+                const int src_w = op.in2_ld, src_h = op.in_rows / op.in2_ld, f = src_w / op.in_w;
+                AVL_REQUIRE(f >= 1 && op.in_w == src_w / f && op.in_h == src_h / f, "stem raw frame %dx%d does not scale to %dx%d by an integer factor",
+                            src_h, src_w, op.in_h, op.in_w);
+            } else {
+                AVL_REQUIRE(op.in_rows >= in_pix, "stem input buffer");
+            }
             return AVL_OK;
         case AVL_OP_GEMV:
             AVL_REQUIRE(op.weight && op.in_c > 0 && op.out_c > 0, "gemv shapes");
@@ -781,15 +744,20 @@ int validate_conv_op(const avl_seg_op& op) {
 int launch_preprocess(const unsigned char* bgr, int H, int W, const double* K, const double* dist, int factor, unsigned char* out,
                       hipStream_t s) {
     PreParams q;
-    memset(&q, 0, sizeof(q));
+    q.cam = make_pre_camera(K, dist);
     q.factor = factor;
-    q.undistort = (K && dist) ? 1 : 0;
-    if (q.undistort) {
-        q.fx = (float)K[0]; q.cx = (float)K[2]; q.fy = (float)K[4]; q.cy = (float)K[5];
-        q.k1 = (float)dist[0]; q.k2 = (float)dist[1]; q.p1 = (float)dist[2]; q.p2 = (float)dist[3]; q.k3 = (float)dist[4];
-    }
     const int OH = H / factor, OW = W / factor;
     hipLaunchKernelGGL(k_preprocess, dim3(blocks_for((long long)OH * OW)), dim3(kThreads), 0, s, bgr, H, W, q, out, OH, OW);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+__global__ void k_set_camera(PreCamera q, PreCamera* out) { *out = q; }
+
+// writes the camera block a pre-processing stem reads (stream-ordered, so a captured plan can switch cameras between frames)
+int launch_set_camera(void* cam_dev, const double* K, const double* dist, hipStream_t s) {
+    static_assert(sizeof(PreCamera) <= 64, "AVL_STEM_CAMERA_BYTES");
+    hipLaunchKernelGGL(k_set_camera, dim3(1), dim3(1), 0, s, make_pre_camera(K, dist), static_cast<PreCamera*>(cam_dev));
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }

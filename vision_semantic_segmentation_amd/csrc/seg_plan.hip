@@ -51,7 +51,7 @@ void work(const avl_seg_op& op, double& flops, double& bytes) {
     switch (op.kind) {
         case AVL_OP_STEM:
             flops = 2.0 * out_pix * 64 * 147;
-            bytes = in_pix * 3 + out_pix * 64 * es;
+            bytes = (op.in2 ? (double)op.in_rows : in_pix) * 3 + out_pix * 64 * es;      // in2: the raw camera frame is what is read
             break;
         case AVL_OP_GEMM:
             flops = 2.0 * out_pix * op.out_c * (op.in_c + (op.in3 ? op.in3_c : 0));
@@ -182,7 +182,15 @@ extern "C" int avl_seg_plan_profile(avl_seg_plan* plan, void* stream, float* ms_
     return AVL_OK;
 }
 
-namespace avl { int launch_preprocess(const unsigned char*, int, int, const double*, const double*, int, unsigned char*, hipStream_t); }
+namespace avl {
+int launch_preprocess(const unsigned char*, int, int, const double*, const double*, int, unsigned char*, hipStream_t);
+int launch_set_camera(void*, const double*, const double*, hipStream_t);
+}
+extern "C" int avl_stem_camera_set(void* camera_dev, const double* K_host, const double* dist_host, void* stream) {
+    AVL_REQUIRE(camera_dev && reinterpret_cast<uintptr_t>(camera_dev) % 4 == 0, "bad camera block");
+    AVL_REQUIRE((K_host == nullptr) == (dist_host == nullptr), "K_host and dist_host go together");
+    return avl::launch_set_camera(camera_dev, K_host, dist_host, avl::as_stream(stream));
+}
 extern "C" int avl_preprocess_image(const uint8_t* bgr, int h, int w, const double* K_host, const double* dist_host, int factor,
                                     uint8_t* rgb_out, void* stream) {
     AVL_REQUIRE(bgr && rgb_out && h > 0 && w > 0, "bad image buffers");

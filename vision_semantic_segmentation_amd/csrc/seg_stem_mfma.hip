@@ -7,7 +7,14 @@
 // 24 are zero weights).  A workgroup converts an input tile (8x32 outputs -> 21x69 pixels) to normalised bf16 in
 // LDS once (zeros outside the image: padding applies to the NORMALISED image), keeps all 24 weight fragments in
 // registers and each wave walks 4 sub-tiles of 16 pixels: 21 LDS reads + 24 v_mfma_f32_16x16x32_bf16 per sub-tile.
+//
+// PRE = the node's pre-processing (vision_semantic_segmentation_node.py:83-98: BGR->RGB, cv2.undistort, INTER_AREA by an
+// integer factor) happens in the loader: `img` is then the RAW camera frame and every pixel of the LDS tile is
+// preprocessed_rgb() of seg_preprocess.h -- the function k_preprocess applies -- so the RGB network input is never written
+// to memory or re-read.  The 5-pixel halo of a tile is recomputed (x1.41 pixels), which costs less than
+// the round trip: the undistortion is ~60 double-precision flops per source pixel.
 #include "seg_types.h"
+#include "seg_preprocess.h"
 
 namespace avl {
 namespace {
@@ -23,9 +30,11 @@ struct StemArgs {
     const float* bias;    // [64]
     HT* out;
     int H, W, OH, OW, out_ld, tiles_x;
+    const PreCamera* cam;      // PRE: device memory (one captured graph serves both cameras)
+    int srcH, srcW, factor;    // PRE: the raw frame; H = srcH / factor, W = srcW / factor
 };
 
-template <typename HT>
+template <typename HT, bool PRE>
 __global__ void __launch_bounds__(256) k_stem_mfma(StemArgs<HT> p) {
     typedef typename Half16<HT>::v8 v8;
     __shared__ __attribute__((aligned(16))) HT tile[(IN_TH + 1) * ROW];
@@ -36,32 +45,54 @@ __global__ void __launch_bounds__(256) k_stem_mfma(StemArgs<HT> p) {
     const int oy0 = ty * S_TH, ox0 = tx * S_TW;
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
-    // all of a lane's byte loads are issued before the first conversion (the element-at-a-time loop was a chain of
-    // ~20 dependent global-load latencies per workgroup and cost more than the MFMAs)
-    constexpr int NE = ((IN_TH + 1) * ROW + 255) / 256;
-    unsigned char px[NE];
-    unsigned okmask = 0;
+    if constexpr (PRE) {
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int e = tid + i * 256;
-        const int ly = e / ROW, lc = e - ly * ROW;
-        const int lx = lc / 3;
-        const int iy = iy0 + ly, ix = ix0 + lx;
-        const bool ok = ly < IN_TH && lx < IN_TW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);      // unconditional load, masked below
-        px[i] = p.img[((long long)cy * p.W + cx) * 3 + (lc - lx * 3)];
-        okmask |= (ok ? 1u : 0u) << i;
-    }
-    // while the loads are in flight: the 768-entry table
+        for (int ci = 0; ci < 3; ++ci) lut[ci * 256 + tid] = (HT)(((float)tid / 255.0f - mean[ci]) / stdv[ci]);
+        // the slack of every row and the extra row (read by the zero-weight pad taps)
+        for (int e = tid; e < (IN_TH + 1) * ROW; e += 256) {
+            const int ly = e / ROW, lc = e - ly * ROW;
+            if (ly >= IN_TH || lc >= IN_TW * 3) tile[e] = (HT)0.f;
+        }
+        const PreCamera cam = *p.cam;
+        __syncthreads();
+        for (int i = tid; i < IN_TH * IN_TW; i += 256) {
+            const int ly = i / IN_TW, lx = i - ly * IN_TW;
+            const int iy = iy0 + ly, ix = ix0 + lx;
+            const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            int rgb[3] = {0, 0, 0};
+            if (ok) preprocessed_rgb(p.img, p.srcH, p.srcW, cam, p.factor, ix, iy, rgb);
+            HT* t = tile + ly * ROW + lx * 3;
 #pragma unroll
-    for (int ci = 0; ci < 3; ++ci) lut[ci * 256 + tid] = (HT)(((float)tid / 255.0f - mean[ci]) / stdv[ci]);
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int e = tid + i * 256;
-        if (e < (IN_TH + 1) * ROW) {
-            const int ci = (e % ROW) % 3;
-            tile[e] = ((okmask >> i) & 1u) ? lut[ci * 256 + px[i]] : (HT)0.f;
+            for (int c = 0; c < 3; ++c) t[c] = ok ? lut[c * 256 + rgb[c]] : (HT)0.f;
+        }
+    } else {
+        // all of a lane's byte loads are issued before the first conversion (the element-at-a-time loop was a chain of
+        // ~20 dependent global-load latencies per workgroup and cost more than the MFMAs)
+        constexpr int NE = ((IN_TH + 1) * ROW + 255) / 256;
+        unsigned char px[NE];
+        unsigned okmask = 0;
+    #pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * 256;
+            const int ly = e / ROW, lc = e - ly * ROW;
+            const int lx = lc / 3;
+            const int iy = iy0 + ly, ix = ix0 + lx;
+            const bool ok = ly < IN_TH && lx < IN_TW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);      // unconditional load, masked below
+            px[i] = p.img[((long long)cy * p.W + cx) * 3 + (lc - lx * 3)];
+            okmask |= (ok ? 1u : 0u) << i;
+        }
+        // while the loads are in flight: the 768-entry table
+    #pragma unroll
+        for (int ci = 0; ci < 3; ++ci) lut[ci * 256 + tid] = (HT)(((float)tid / 255.0f - mean[ci]) / stdv[ci]);
+        __syncthreads();
+    #pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * 256;
+            if (e < (IN_TH + 1) * ROW) {
+                const int ci = (e % ROW) % 3;
+                tile[e] = ((okmask >> i) & 1u) ? lut[ci * 256 + px[i]] : (HT)0.f;
+            }
         }
     }
     const int fr = lane & 15, kq = lane >> 4;
@@ -130,7 +161,14 @@ int launch_stem_typed(const avl_seg_op& op, hipStream_t s) {
     a.H = op.in_h; a.W = op.in_w; a.OH = op.out_h; a.OW = op.out_w; a.out_ld = op.out_ld;
     a.tiles_x = (op.out_w + S_TW - 1) / S_TW;
     const int tiles_y = (op.out_h + S_TH - 1) / S_TH;
-    hipLaunchKernelGGL(k_stem_mfma<HT>, dim3(a.tiles_x * tiles_y), dim3(256), 0, s, a);
+    a.cam = static_cast<const PreCamera*>(op.in2);
+    a.srcW = op.in2_ld;
+    a.srcH = op.in2_ld > 0 ? op.in_rows / op.in2_ld : 0;
+    a.factor = op.in_w > 0 ? a.srcW / op.in_w : 1;
+    if (op.in2)
+        hipLaunchKernelGGL((k_stem_mfma<HT, true>), dim3(a.tiles_x * tiles_y), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((k_stem_mfma<HT, false>), dim3(a.tiles_x * tiles_y), dim3(256), 0, s, a);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }

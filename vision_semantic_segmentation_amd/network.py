@@ -413,11 +413,20 @@ class SegNet(object):
     ROW_PAD = 256        # GEMM tiles read whole 128/256-row tiles
     MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx", "dw_exact")    # keyword switches of the "mixed" mode
 
-    def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8, fuse_dwpw=True, **mixed_opts):
+    def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8, fuse_dwpw=True, raw_frame=None,
+                 **mixed_opts):
+        """raw_frame = (src_h, src_w): the plan's input is the RAW BGR camera frame and the node's pre-processing
+        (vision_semantic_segmentation_node.py:83-98: BGR->RGB, undistort, INTER_AREA by src_w // width) runs inside the stem's loader
+        (16-bit precisions); ``set_camera`` chooses the camera model, ``forward`` takes the raw frame."""
         assert output_stride == 8, "the reference configuration is OS8 (base_cfg.py:106)"
         assert precision in ("bf16", "f16", "f32", "mixed")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.H, self.W = int(height), int(width)
+        self.raw_frame = None if raw_frame is None else (int(raw_frame[0]), int(raw_frame[1]))
+        if self.raw_frame is not None:
+            f = self.raw_frame[1] // self.W
+            if precision == "f32" or f < 1 or (self.raw_frame[0] // f, self.raw_frame[1] // f) != (self.H, self.W):
+                raise ValueError("raw_frame %r does not scale to %dx%d by an integer factor (or precision is f32)" % (self.raw_frame, self.H, self.W))
         self.precision = precision
         # "mixed": f16 MFMA with split operands where the error analysis (tools/precision_study.py, DESIGN.md section 4)
         # says a single f16 rounding is too coarse: every weight is an f16 pair hi + lo, the residual trunk, the ASPP
@@ -627,9 +636,11 @@ class SegNet(object):
     def _build(self, st):
         H, W = self.H, self.W
         dev = self.device
-        self.image = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+        # the plan's input: the RGB network input, or the raw BGR camera frame when the stem pre-processes
+        self.image = torch.zeros((H, W, 3) if self.raw_frame is None else self.raw_frame + (3,), dtype=torch.uint8, device=dev)
         self.zero_page = torch.zeros(64, dtype=torch.uint8, device=dev)          # what a depthwise tap outside the image reads
-        self._keep += [self.image, self.zero_page]
+        self.camera_block = torch.zeros(64, dtype=torch.uint8, device=dev)       # AVL_STEM_CAMERA_BYTES: zeros = no undistortion
+        self._keep += [self.image, self.zero_page, self.camera_block]
 
         # ---- stem: conv1 7x7 s2 + bn1 + relu (resnet.py:25-27), maxpool (:28)
         h2, w2 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
@@ -640,9 +651,10 @@ class SegNet(object):
             w_stem, stem_layout = self._dev(w.permute(2, 3, 1, 0).reshape(-1), torch.float32), 0   # [ky][kx][ci][co]
         b_stem = self._dev(b, torch.float32)
         stem = self._act(h2 * w2, 64)
+        raw = {} if self.raw_frame is None else dict(in2=self.camera_block.data_ptr(), in2_ld=self.raw_frame[1])
         self._op("backbone.conv1", OP_STEM, in_=self.image.data_ptr(), out=stem.hi.data_ptr(), weight=w_stem.data_ptr(),
-                 bias=b_stem.data_ptr(), in_h=H, in_w=W, in_c=3, in_ld=3, in_rows=H * W, out_h=h2, out_w=w2, out_c=64,
-                 out_ld=64, out_rows=stem.shape[0], ksize=7, stride=2, pad=3, dil=1, groups=1, relu=1, w_layout=stem_layout)
+                 bias=b_stem.data_ptr(), in_h=H, in_w=W, in_c=3, in_ld=3, in_rows=self.image.shape[0] * self.image.shape[1], out_h=h2, out_w=w2,
+                 out_c=64, out_ld=64, out_rows=stem.shape[0], ksize=7, stride=2, pad=3, dil=1, groups=1, relu=1, w_layout=stem_layout, **raw)
         h4, w4 = (h2 + 2 - 3) // 2 + 1, (w2 + 2 - 3) // 2 + 1
         x = self._act(h4 * w4, 64)
         self._spatial("backbone.maxpool", OP_MAXPOOL, stem, (h2, w2), 64, x, (h4, w4), 64, ksize=3, stride=2, pad=1, dil=1)
@@ -866,12 +878,25 @@ class SegNet(object):
         """float32 CUDA tensor [out_h, out_w, K] of the last forward (NHWC)."""
         return self.logits_buf[:self.out_h * self.out_w].view(self.out_h, self.out_w, self.num_classes)
 
+    def set_camera(self, K=None, dist=None, stream=None):
+        """raw_frame plans: the camera model the stem undistorts with (3x3 K, k1 k2 p1 p2 k3); None = no undistortion.
+        Stream-ordered, so it may change between two forwards of a captured plan."""
+        assert self.raw_frame is not None, "set_camera needs a plan built with raw_frame"
+        assert (K is None) == (dist is None)
+        k = d = None
+        if K is not None:
+            k = (C.c_double * 9)(*np.asarray(K, dtype=np.float64).ravel().tolist())
+            d = (C.c_double * 5)(*np.asarray(dist, dtype=np.float64).ravel()[:5].tolist())
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        _lib.check(_lib.lib().avl_stem_camera_set(C.c_void_p(self.camera_block.data_ptr()), k, d, C.c_void_p(s)), "avl_stem_camera_set")
+
     def forward(self, image_u8=None, stream=None):
-        """image_u8: CUDA/CPU uint8 [H,W,3] RGB (copied into the plan's input buffer) or None to reuse it."""
+        """image_u8: CUDA/CPU uint8 [H,W,3] RGB -- or, for a raw_frame plan, the [src_h,src_w,3] BGR camera frame -- (copied
+        into the plan's input buffer) or None to reuse it."""
         if image_u8 is not None:
             if not isinstance(image_u8, torch.Tensor):
                 image_u8 = torch.from_numpy(np.ascontiguousarray(image_u8))
-            assert tuple(image_u8.shape) == (self.H, self.W, 3) and image_u8.dtype == torch.uint8
+            assert tuple(image_u8.shape) == tuple(self.image.shape) and image_u8.dtype == torch.uint8
             self.image.copy_(image_u8, non_blocking=True)
         s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
         _lib.check(_lib.lib().avl_seg_plan_run(self._plan, C.c_void_p(s)), "avl_seg_plan_run")

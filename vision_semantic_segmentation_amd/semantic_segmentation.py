@@ -41,11 +41,13 @@ class SemanticSegmentation(object):
         check_state_dict(self.state, **kw)
         self._nets = {}
 
-    def net_for(self, h, w):
-        """The compiled plan for an h x w input (built on first use, kept per size)."""
-        key = (int(h), int(w))
+    def net_for(self, h, w, raw_frame=None):
+        """The compiled plan for an h x w network input (built on first use, kept per size).  raw_frame = (src_h, src_w): the plan
+        that takes the raw BGR camera frame and pre-processes inside its first kernel."""
+        key = (int(h), int(w)) if raw_frame is None else (int(h), int(w), int(raw_frame[0]), int(raw_frame[1]))
         if key not in self._nets:
             net = SegNet(self.state, key[0], key[1], precision=self.precision, device=self.device, num_classes=self.num_classes,
+                         raw_frame=raw_frame,
                          conv2_split=bool(getattr(self.cfg.MODEL, "MIXED_CONV2_SPLIT", True)),
                          gconv_mx=bool(getattr(self.cfg.MODEL, "MIXED_GCONV_MX", True)),
                          trunk_fp4=bool(getattr(self.cfg.MODEL, "MIXED_TRUNK_FP4", True)))
@@ -59,6 +61,18 @@ class SemanticSegmentation(object):
         h, w = int(image_in.shape[0]), int(image_in.shape[1])
         net = self.net_for(h, w)
         return net.forward(image_in)
+
+    def segmentation_device_raw(self, bgr, K=None, dist=None, factor=1):
+        """The node's chain from the camera frame on (vision_semantic_segmentation_node.py:83-102) in the network's own kernels:
+        uint8 BGR [H,W,3] (ndarray or CUDA tensor) -> BGR->RGB, cv2.undistort(K, dist) (skipped when None), INTER_AREA by the integer
+        `factor`, normalise, network, arg-max -> uint8 CUDA tensor.  Same labels as preprocess_device() + segmentation_device(), without
+        the RGB frame in between."""
+        if self.precision == "f32":
+            raise NotImplementedError("the pre-processing stem is a 16-bit MFMA kernel; use preprocess_device() with PRECISION f32")
+        H, W = int(bgr.shape[0]), int(bgr.shape[1])
+        net = self.net_for(H // factor, W // factor, raw_frame=(H, W))
+        net.set_camera(K, dist)
+        return net.forward(bgr)
 
     def segmentation(self, image_in):
         """semantic_segmentation.py:41-57: numpy (h, w, 3) RGB -> int64 numpy label map."""

@@ -3,8 +3,9 @@
 
 image_callback keeps the reference's sequence (:74-136): BGR->RGB, cv2.undistort, optional INTER_AREA downscale,
 ``SemanticSegmentation.segmentation``, uint8 cast, INTER_NEAREST upscale to the input size, palette
-colouring, publish.  Pre-processing is one HIP kernel (avl_preprocess_image), the upscale + colouring another
-(avl_colorize_labels); the frame is uploaded once and only the colour image comes back.
+colouring, publish.  Pre-processing runs inside the network's first kernel (the stem's loader applies BGR->RGB, undistort and
+INTER_AREA per pixel while it fills its LDS tile; avl_preprocess_image is the same function as a stand-alone kernel), the
+upscale + colouring is one more kernel (avl_colorize_labels); the frame is uploaded once and only the colour image comes back.
 """
 import ctypes as C
 import threading
@@ -132,8 +133,12 @@ class VisionSemanticSegmentationNode(object):
         h, w = int(bgr.shape[0]), int(bgr.shape[1])
         cam = {"camera1": self.cam1, "camera6": self.cam6}.get(msg.header.frame_id)   # unknown frame ids: no undistortion (:88-89)
         with self._lock:
-            rgb_small = preprocess_device(bgr, cam if self.undistort else None, self._downscale_factor())
-            labels = self.seg.segmentation_device(rgb_small)
+            cam = cam if self.undistort else None
+            if self.seg.precision == "f32":                      # no 16-bit stem: stand-alone pre-processing kernel, then the network
+                labels = self.seg.segmentation_device(preprocess_device(bgr, cam, self._downscale_factor()))
+            else:                                                # pre-processing inside the stem's loader (no RGB frame in between)
+                labels = self.seg.segmentation_device_raw(bgr, None if cam is None else cam.K, None if cam is None else cam.dist,
+                                                          self._downscale_factor())
             self.last_labels = labels
             colored = colorize_labels_device(labels, h, w, self.seg_color_ref)
             out = colored.cpu().numpy()
