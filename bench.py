@@ -247,7 +247,7 @@ def gemm_roofline(net, precision):
     peak = PEAK_F32_TFLOPS if precision == "f32" else PEAK_MFMA16_TFLOPS
     achieved = g_fl / g_ms / 1e9
     traffic, traffic_note = pmc_traffic(len(gemm), precision)
-    return {"bound": "mfma", "kernel": "k_gemm_ring / k_gemm (1x1 conv, %d launches/frame)" % len(gemm), "achieved": round(achieved, 1),
+    return {"bound": "mfma", "kernel": "k_gemm_mx_pipe (MX GEMMs) / k_gemm_ring / k_gemm: the 1x1 convs, %d launches/frame" % len(gemm), "achieved": round(achieved, 1),
             "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
             "executed_tflops": round(g_exec / g_ms / 1e9, 1), "executed_frac": round(g_exec / g_ms / 1e9 / peak, 4),
             "algorithmic_bytes_per_frame": sum(p["bytes"] for p, _ in gemm),
