@@ -20,12 +20,12 @@ SHAPES = [  # (name, M, K, N, residual)
 ]
 
 
-def run(name, M, K, N, res, variant, reps, check):
+def run(name, M, K, N, res, variant, reps, check, pad=0):
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     Mp = (M + 255) // 256 * 256
     Np = (N + 255) // 256 * 256
-    a = torch.randn(Mp, K, device=dev).to(torch.bfloat16)
+    a = torch.randn(Mp, K + pad, device=dev).to(torch.bfloat16)[:, :K]         # pad: row pitch of the activations (L2 channel experiment)
     if os.environ.get("AVL_ZERO"):          # zero operands draw less power: separates clock limits from schedule limits
         a.zero_()
     w = (torch.randn(Np, K, device=dev) / K ** 0.5).to(torch.bfloat16)
@@ -35,7 +35,7 @@ def run(name, M, K, N, res, variant, reps, check):
     op = AvlSegOp()
     op.kind, op.dtype = OP_GEMM, _lib.AVL_BF16
     op.in_, op.out, op.weight, op.bias = a.data_ptr(), out.data_ptr(), w.data_ptr(), b.data_ptr()
-    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = 1, M, K, K, Mp
+    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = 1, M, K, K + pad, Mp
     op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = 1, M, N, N, Mp
     op.relu, op.w_rows, op.ksize, op.stride, op.dil, op.groups = 1, Np, 1, 1, 1, 1
     op.w_layout = variant
@@ -72,9 +72,10 @@ if __name__ == "__main__":
     ap.add_argument("--variants", default="1,0")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--pad", type=int, default=0, help="extra elements per activation row (in_ld = K + pad)")
     a = ap.parse_args()
     tot = {}
     for sh in SHAPES:
         for v in [int(x) for x in a.variants.split(",")]:
-            tot[v] = tot.get(v, 0.0) + run(*sh, variant=v, reps=a.reps, check=not a.no_check)
+            tot[v] = tot.get(v, 0.0) + run(*sh, variant=v, reps=a.reps, check=not a.no_check, pad=a.pad)
     print("sum over shapes (ms):", {k: round(v, 4) for k, v in tot.items()})

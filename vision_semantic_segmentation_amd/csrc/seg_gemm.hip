@@ -958,7 +958,9 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
 // Sub-step kinds (f16 / FP4) alternate inside the stream; the fragments carried across a boundary are plain 128-bit values.
 // MI = 4 (128 x 256 tiles): one event (both slots) in front of step 5 of 8, vmcnt(0).
 // PROBE (timing experiments, results are garbage): 1 = no DMA after the prologue, 2 = no MFMAs, 3 = s_memtime stamps around the
-// events and the DMA bursts, per-wave sums -> q.dbg (each stamp drains the LDS queue: read the SHARES, not the totals)
+// events and the DMA bursts, per-wave sums -> q.dbg (each stamp drains the LDS queue: read the SHARES, not the totals),
+// 4 = no weight-fragment LDS reads after the first two sub-steps (a third of the LDS read bytes), 5 = every other activation
+// fragment not read (another third)
 template <int IO, int MI, int LATE, int PROBE = 0>
 __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
     typedef f16 H;
@@ -1211,8 +1213,10 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             if (PROBE == 3) { t1 = stamp(); tsum[3] += t1 - t0; }
             if (PROBE != 1 && early && pt < total) { if (EW == EV) issue_w(); issue_a(); }
             if (PROBE == 3) tsum[4] += stamp() - t1;
+            if (PROBE != 4 || g < 2) {
 #pragma unroll
-            for (int nj = 0; nj < 4; ++nj) Wf[0][nj] = rdW(wbn, 0, nj);
+                for (int nj = 0; nj < 4; ++nj) Wf[0][nj] = rdW(wbn, 0, nj);
+            }
             if (next_q) Wsn = rdWs(sbn);
             readAn(0);
         }
@@ -1225,10 +1229,10 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
         }
         // activation fragments: D steps ahead, one per step -- the last one of the slot at step EV - 1, the first of the next slot
         // right behind the event
-        if (S + D < NS) readA(S + D);
+        if (S + D < NS && (PROBE != 5 || g < 2 || ((S + D) & 1) == 0)) readA(S + D);
         if (S >= EV && S + 1 < NS) readAn(S - EV + 1);
         // weight fragments of the second K half
-        if constexpr (MI == 8 && S < 4) Wf[1][S] = rdW(wb, 1, S);
+        if constexpr (MI == 8 && S < 4) if (PROBE != 4 || g < 2) Wf[1][S] = rdW(wb, 1, S);
         if constexpr (MI == 4 && S < 2) { Wf[1][2 * S] = rdW(wb, 1, 2 * S); Wf[1][2 * S + 1] = rdW(wb, 1, 2 * S + 1); }
         if (KIND == 0) {
             const v8 af = __builtin_bit_cast(v8, Af[S]);
@@ -1315,6 +1319,8 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
     } while (0)
         if (MI == 8 && probe == 1) AVL_PIPE_LAUNCH(IO, 8, 0, 1);
         else if (MI == 8 && probe == 2) AVL_PIPE_LAUNCH(IO, 8, 0, 2);
+        else if (MI == 8 && probe == 4) AVL_PIPE_LAUNCH(IO, 8, 0, 4);
+        else if (MI == 8 && probe == 5) AVL_PIPE_LAUNCH(IO, 8, 0, 5);
         else if (MI == 8 && probe == 3) {
             static unsigned long long* dbg = nullptr;
             if (!dbg) AVL_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&dbg), 256 * 8 * 8 * sizeof(unsigned long long), 0));
