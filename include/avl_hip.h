@@ -235,7 +235,11 @@ int avl_eval_map(const uint8_t* color_map, int H, int W, const uint8_t* mask, in
                                 weight/bias = the 1x1 conv's (as AVL_OP_GEMM); in2 = depthwise parameters packed
                                 [K/64][8][6][8] dwords: five tap pairs (taps 2p | 2p+1 << 16 in the activation type)
                                 and the fp32 bias of each 8-channel chunk; then int32[ceil(H*W/128)]: the order in
-                                which the 128-pixel tiles are visited (a permutation; tiles a dilation apart adjacent) */
+                                which the 128-pixel tiles are visited (a permutation; tiles a dilation apart adjacent).
+                                w_split = 2 (AVL_F16): the EXACT depthwise stage -- depthwise weights as f16 pairs hi + lo
+                                and a split depthwise result; in2 = [K/64][8][11][8] dwords per 8-channel chunk: five
+                                tap pairs of the hi parts, five of the lo parts, the fp32 bias; then the tile order as
+                                above.  `weight` is the 1x1 conv's [n][K/64][hi 64 | lo 64] as for w_split = 1. */
 
 typedef struct avl_seg_op {
     int32_t kind;            /* AVL_OP_*                                                        */
@@ -275,6 +279,11 @@ typedef struct avl_seg_op {
      * An "MX bundle" of a [rows][C] tensor (C % 256 == 0, dense rows) is laid out
      *     [FP4 plane of the hi part: rows x C/2 bytes][its scales: C/256 x rows x 8 bytes][the same two for the lo part]
      * w_mx: bundle of the weights (rows = w_rows; first Q4(W lo), then Q4(W hi)); in_mx: bundle of the input (rows = in_rows);
+     * the WEIGHT bundle's scale arrays are permuted inside every 16-row block (network.permute_w_scales): for a 256-wide K block
+     * the 128 scale bytes of rows r0..r0+15 are stored [row & 3][k quarter kq 0..3][n-tile (row >> 2) & 3][k half kk 0..1], i.e.
+     * byte ((row & 3) * 4 + kq) * 8 + 2 * ((row >> 2) & 3) + kk holds the scale of row r0 + (row) for K block 4 kk + kq of the
+     * eight 32-wide blocks: the eight bytes a lane of the kernel needs in a sub-step are then one aligned 8-byte word.
+     * Activation bundles keep the natural [C/256][rows][8] order.
      * out_mx (GEMM with w_split = 2, or GCONV with w_split = 1): the op also writes the bundle of its OUTPUT (rows = out_rows;
      * the lo half only if out_lo is set), which is what the next MX GEMM reads as in_mx.
      * A tensor may keep its lo part ONLY as the FP4 half of its bundle (no f16 lo plane: 3 instead of 5 bytes per element
@@ -283,7 +292,8 @@ typedef struct avl_seg_op {
      * term that is 2^-11 of the sum); AVL_MX_OUT_LO = write the lo half of out_mx although out_lo is NULL.
      * A SECOND input (GEMM, w_split = 2): in3 [rows][in3_c] (row stride in3_ld, bundle in3_mx, same rows as `in`) is appended
      * along K -- out = W[:, :in_c] . in + W[:, in_c:] . in3: a Bottleneck's conv3 and its downsample 1x1 (stride 1) in ONE
-     * product, the identity tensor never exists.  `weight` / `w_mx` then hold the concatenated [w_rows][in_c + in3_c] matrix. */
+     * product, the identity tensor never exists.  `weight` / `w_mx` then hold the concatenated [w_rows][in_c + in3_c] matrix.
+     * in3 must be a dense tensor of its own (in3_ld == in3_c: its bundle's planes are addressed with that pitch). */
     const void* w_mx;
     const void* in_mx;
     void* out_mx;

@@ -10,7 +10,8 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")
 from oracle import network_oracle as no  # noqa: E402
 from vision_semantic_segmentation_amd.network import SegNet, random_state_dict  # noqa: E402
 
-cases = [(0, 1, 480, 640), (0, 2, 480, 640), (1, 0, 480, 640), (2, 3, 480, 640), (1, 1, 1080, 1920), (0, 5, 1080, 1920)]
+cases = [(0, 1, 480, 640), (0, 2, 480, 640), (1, 0, 480, 640), (2, 3, 480, 640), (4, 0, 480, 640), (4, 1, 480, 640), (5, 0, 480, 640), (5, 1, 480, 640),
+         (1, 1, 1080, 1920), (0, 5, 1080, 1920), (2, 3, 1080, 1920), (2, 7, 1080, 1920)]
 # usage: seed_sweep.py [key=0|1,...|-] [wide]   (mixed-mode builder options, e.g. gconv_mx=1 or trunk_fp4=0; "wide": 16 more 480 x 640 cases)
 opts = {kv.split("=")[0]: bool(int(kv.split("=")[1])) for kv in (sys.argv[1].split(",") if len(sys.argv) > 1 and sys.argv[1] != "-" else []) if kv}
 if len(sys.argv) > 2 and sys.argv[2] == "wide":
