@@ -1306,7 +1306,12 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
     const int mtiles = (a.g.M + BM - 1) / BM;
     const int total = mtiles * a.g.ntiles;
     const int grid = total < 256 ? total : 256;
-    static const int pipe = getenv("AVL_MX_PIPE") ? atoi(getenv("AVL_MX_PIPE")) : 1;          // 0: the round-2 kernel (A/B experiments)
+    // Which main loop: the software-pipelined stream wins where the K loop is long (K >= 1024: -2...-9 % on layer4 / layer3 conv1
+    // and conv3 + downsample), the round-2 kernel (two plain barriers per sub-step, a cheaper tile switch) where a tile is only 1-2 K
+    // macro-blocks (K = 256 / 512: layer2, layer3 conv3, the decoder's pointwise convs: the stream is +2...+19 % there);
+    // profiles/r03/gemm_mx_pipe_vs_ring_ab.log.  AVL_MX_PIPE = 0 / 1 forces one of them (A/B experiments).
+    static const int pipe_env = getenv("AVL_MX_PIPE") ? atoi(getenv("AVL_MX_PIPE")) : -1;
+    const bool pipe = pipe_env >= 0 ? pipe_env != 0 : a.g.K >= 1024;
     static const int late_env = getenv("AVL_MX_LATE") ? atoi(getenv("AVL_MX_LATE")) : -1;
     if (pipe) {
         // LATE: how many steps behind the event(s) waves 0-3 issue their bursts (waves 4-7: right behind them)
