@@ -46,6 +46,8 @@ struct GconvArgs {
     const char* xq[2];   // FP4 planes of the input [rows][C/2]: hi part, lo part (NULL: no lo correction)
     const char* xs[2];   // scales [C/256][rows][8]
     long long x_srows;
+    int dephase;               // 1: waves 4-7 stage the next tile in the middle of their MFMA phase (A/B switch AVL_GC_DEPHASE)
+    unsigned long long* dbg;   // AVL_GC_PROBE=1: per-wave cycle sums of the tile loop's phases (host-visible memory), else NULL
 };
 
 // WS = 1 ("mixed" precision): the weights come as f16 pairs hi + lo ([window][nj 2][tap 18 = 9 hi, 9 lo][16][32]); both
@@ -94,13 +96,15 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
     const int n64 = (npix + 63) >> 6;
     const int QBASE = ngroups * 1024, QT = n64 * 1024, SBASE = QBASE + 4 * QT, ST = n64 * 256;
     const bool has_lo = WS == 2 && p.xq[1] != nullptr;
-    const int nplanes = has_lo ? 2 : 1;
 
     // ---- stage one input tile (+halo) by LDS-DMA: one wave-instruction = 8 pixels x 128 B, all of a wave's transfers in
     // flight at once.  The DMA writes LDS lane-linearly, so the chunk swizzle goes on the SOURCE address.  Pixels outside
     // the image are fetched from a clamped address and zeroed once the data has landed (bit mask returned).  The DMA is
     // issued from inline asm: the compiler does not see it, so it neither drains it in front of the ds_reads of the OTHER
     // buffer nor needs to -- completion is the hand-placed s_waitcnt vmcnt(0) at the top of the tile loop.
+    const char* const xq0 = p.xq[0];
+    const char* const xs0 = p.xs[0];
+    const long long xq_delta = has_lo ? p.xq[1] - p.xq[0] : 0, xs_delta = has_lo ? p.xs[1] - p.xs[0] : 0;
     auto stage = [&](int sp, int buf) -> unsigned {
         const int tx = sp % p.tiles_x, r1 = sp / p.tiles_x;
         const int ty = r1 % p.tiles_y, cmb = r1 / p.tiles_y;
@@ -109,38 +113,44 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
         const int prow = lane >> 3, cphys = lane & 7;
         unsigned oob = 0;
         int it = 0;
+        // (branch-free: `&&` chains compile to a saveexec / branch ladder per DMA instruction; unsigned compares fold the >= 0 tests)
         for (int gi = wave; gi < ngroups; gi += 8, ++it) {
             const int pix = gi * 8 + prow;
             const int ly = (pix * p.tw_magic) >> 16, lx = pix - ly * in_tw;     // pix / in_tw (exact for the tile sizes: checked on the host)
             const int iy = iy0 + ly * step, ix = ix0 + lx * step;
-            const bool inside = pix < npix && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const unsigned outside = (unsigned)(pix >= npix) | (unsigned)((unsigned)iy >= (unsigned)p.H) | (unsigned)((unsigned)ix >= (unsigned)p.W);
             const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
             // uniform base (plane + channel chunk) + 32-bit lane offset
             const unsigned voff = ((unsigned)(cy * p.W + cx) * (unsigned)p.in_ld + ((cphys ^ (pix & 7)) << 3)) * (unsigned)sizeof(HT);
             glds16_saddr(p.in + c0, voff, lds0 + buf * p.tile_bytes + gi * 1024);
-            oob |= (inside ? 0u : 1u) << it;
+            oob |= outside << it;
         }
         if constexpr (WS == 2) {
-            // FP4 tiles: item = (plane, window, 64-pixel group); lane = pixel; out-of-image pixels are zeroed later (bits 16+)
+            // FP4 tiles: item = (64-pixel group, plane, window) -- the (plane, window) pair in the low bits, so the split is a mask and
+            // a shift (a run-time division by n64 is ~16 scalar instructions per item); lane = pixel; out-of-image pixels are zeroed
+            // later (bits 16+)
+            const int pwbits = has_lo ? 2 : 1;
             it = 16;
-            for (int item = wave; item < nplanes * 2 * n64; item += 8, ++it) {
-                const int gq = item % n64, pw = item / n64, w = pw & 1, pl = pw >> 1;
+            for (int item = wave; item < (n64 << pwbits); item += 8, ++it) {
+                const int pw = item & ((1 << pwbits) - 1), gq = item >> pwbits, w = pw & 1, pl = pw >> 1;
                 const int pix = gq * 64 + lane;
                 const int ly = (pix * p.tw_magic) >> 16, lx = pix - ly * in_tw;
                 const int iy = iy0 + ly * step, ix = ix0 + lx * step;
-                const bool inside = pix < npix && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const unsigned outside = (unsigned)(pix >= npix) | (unsigned)((unsigned)iy >= (unsigned)p.H) | (unsigned)((unsigned)ix >= (unsigned)p.W);
                 const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-                glds16_saddr(p.xq[pl] + c0 / 2 + w * 16, (unsigned)(cy * p.W + cx) * (unsigned)(p.C / 2),
+                // (plane pointer = first plane + pl * distance, not p.xq[pl]: a dynamically indexed kernel argument -- or a select
+                // between two of them -- becomes a scalar load + lgkmcnt(0) per item)
+                glds16_saddr(xq0 + pl * xq_delta + c0 / 2 + w * 16, (unsigned)(cy * p.W + cx) * (unsigned)(p.C / 2),
                              lds0 + buf * p.tile_bytes + QBASE + (pl * 2 + w) * QT + gq * 1024);
-                oob |= (inside ? 0u : 1u) << it;
+                oob |= outside << it;
             }
             // one scale dword per pixel and plane (the four windows of this 128-channel half); a clamped pixel's scales are valid
-            for (int item = wave; item < nplanes * n64; item += 8) {
-                const int gq = item % n64, pl = item / n64;
+            for (int item = wave; item < (n64 << (pwbits - 1)); item += 8) {
+                const int pl = item & ((1 << (pwbits - 1)) - 1), gq = item >> (pwbits - 1);
                 const int pix = gq * 64 + lane;
                 const int ly = (pix * p.tw_magic) >> 16, lx = pix - ly * in_tw;
                 const int cy = min(max(iy0 + ly * step, 0), p.H - 1), cx = min(max(ix0 + lx * step, 0), p.W - 1);
-                glds4_saddr(p.xs[pl] + ((long long)(c0 >> 8) * p.x_srows) * 8 + ((c0 >> 5) & 4), (unsigned)(cy * p.W + cx) * 8u,
+                glds4_saddr(xs0 + pl * xs_delta + ((long long)(c0 >> 8) * p.x_srows) * 8 + ((c0 >> 5) & 4), (unsigned)(cy * p.W + cx) * 8u,
                             lds0 + buf * p.tile_bytes + SBASE + pl * ST + gq * 256);
             }
         }
@@ -197,10 +207,11 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
             for (int gi = wave; gi < ngroups; gi += 8, ++it)
                 if ((mask >> it) & 1u) *reinterpret_cast<uint4*>(lds + b * p.tile_bytes + gi * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
             if constexpr (WS == 2) {
+                const int pwbits = has_lo ? 2 : 1;
                 it = 16;
-                for (int item = wave; item < nplanes * 2 * n64; item += 8, ++it)
+                for (int item = wave; item < (n64 << pwbits); item += 8, ++it)
                     if ((mask >> it) & 1u) {
-                        const int gq = item % n64, pw = item / n64;
+                        const int pw = item & ((1 << pwbits) - 1), gq = item >> pwbits;
                         *reinterpret_cast<uint4*>(lds + b * p.tile_bytes + QBASE + pw * QT + gq * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
                     }
             }
@@ -233,12 +244,27 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
     // Per tile: [DMA of the next tile -> other buffer] [MFMA phase: this wave's sub-tiles, results stay in registers]
     // [s_waitcnt vmcnt(0): the next tile has landed -- the only older stores are those of the PREVIOUS tile, long retired, so
     // the wait never sits on fresh stores] [epilogue phase: bias, ReLU, hi/lo split, FP4 copies, stores] [barrier].
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};     // probe: [0] stage [1] MFMA phase [2] landing wait + zeroing [3] epilogue [4] barrier [5] tiles
+    auto stamp = [&]() __attribute__((always_inline)) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return t;
+    };
     for (; sp < p.nsp; sp += p.nslots, buf ^= 1) {
-        oob = sp + p.nslots < p.nsp ? stage(sp + p.nslots, buf ^ 1) : 0u;
+        unsigned long long t0 = 0, t1 = 0;
+        if (p.dbg) t0 = stamp();
+        // The two waves of a SIMD (w and w + 4) stage the next tile at DIFFERENT points: waves 0-3 in front of their MFMA phase,
+        // waves 4-7 in the middle of theirs -- the staging is ~40 vector instructions per DMA instruction (pixel -> clamped source
+        // address), so one wave of the SIMD computes addresses while the other one's MFMAs run.
+        const bool late_stage = NJ >= 2 && wave >= 4 && p.dephase;
+        oob = 0u;
+        if (!late_stage && sp + p.nslots < p.nsp) oob = stage(sp + p.nslots, buf ^ 1);
+        if (p.dbg) { t1 = stamp(); tsum[0] += t1 - t0; t0 = t1; }
         const char* tile = lds + buf * p.tile_bytes;
         f32x4 acc[NJ][2];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
+            if (NJ >= 2 && j == NJ / 2 && late_stage && sp + p.nslots < p.nsp) oob = stage(sp + p.nslots, buf ^ 1);
             // all nine tap fragments are requested before the first MFMA: the LDS latency is paid once per sub-tile
             v8 a[9];
             if constexpr (HOIST) {
@@ -308,8 +334,10 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
             acc[j][0] = acc0; acc[j][1] = acc1;
             __builtin_amdgcn_sched_barrier(0);      // keep the next sub-tile's nine fragments out of this one's registers
         }
+        if (p.dbg) { t1 = stamp(); tsum[1] += t1 - t0; t0 = t1; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         zero_oob(oob, buf ^ 1);
+        if (p.dbg) { t1 = stamp(); tsum[2] += t1 - t0; t0 = t1; }
 
         const int tx = sp % p.tiles_x, r1 = sp / p.tiles_x;
         const int ty = r1 % p.tiles_y, cmb = r1 / p.tiles_y;
@@ -391,7 +419,13 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (p.dbg) { t1 = stamp(); tsum[3] += t1 - t0; t0 = t1; }
         __syncthreads();
+        if (p.dbg) { t1 = stamp(); tsum[4] += t1 - t0; tsum[5] += 1; }
+    }
+    if (p.dbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) p.dbg[((size_t)blockIdx.x * 8 + wave) * 6 + i] = tsum[i];
     }
 }
 
@@ -499,11 +533,30 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
         AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv_mfma<HT, WS, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_gconv_mfma<HT, WS, NJ>), dim3(a.nslots * a.cchunks), dim3(512), 2 * a.tile_bytes, s, a);             \
     } while (0)
+    static const int dephase = getenv("AVL_GC_DEPHASE") ? atoi(getenv("AVL_GC_DEPHASE")) : 1;
+    a.dephase = dephase;
+    a.dbg = nullptr;
+    static const int probe = getenv("AVL_GC_PROBE") ? atoi(getenv("AVL_GC_PROBE")) : 0;       // timing experiment: where do a wave's cycles go
+    static unsigned long long* dbg = nullptr;
+    if (probe) {
+        if (!dbg) AVL_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&dbg), 256 * 8 * 6 * sizeof(unsigned long long), 0));
+        memset(dbg, 0, 256 * 8 * 6 * sizeof(unsigned long long));
+        if (a.nslots * a.cchunks <= 256) a.dbg = dbg;
+    }
     if (a.th == 8) AVL_GCONV_LAUNCH(4);
     else if (a.th == 4) AVL_GCONV_LAUNCH(2);
     else AVL_GCONV_LAUNCH(1);
 #undef AVL_GCONV_LAUNCH
     AVL_LAUNCH_CHECK();
+    if (a.dbg) {
+        AVL_HIP_CHECK(hipStreamSynchronize(s));
+        double sum[6] = {};
+        for (int i = 0; i < a.nslots * a.cchunks * 8; ++i)
+            for (int k = 0; k < 6; ++k) sum[k] += (double)dbg[i * 6 + k];
+        const double n = sum[5] > 0 ? sum[5] : 1;
+        fprintf(stderr, "[gconv probe] C %d dil %d stride %d th %d WS %d tiles/wg %.1f: cycles per tile: stage %.0f | MFMA phase %.0f | landing wait + zeroing %.0f | epilogue %.0f | barrier %.0f\n",
+                a.C, a.dil, a.stride, a.th, WS, n / (a.nslots * a.cchunks * 8), sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n);
+    }
     return AVL_OK;
 }
 
