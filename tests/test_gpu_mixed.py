@@ -414,6 +414,10 @@ def _unbundle(buf, rows, c, half):
     (66000, 512, 256, True, None, False, False, True),        # conv1-like: both corrections (128-row tiles: 258 x 1 tiles of 256)
     (300, 2048, 2048, True, False, True, True, False),        # fewer rows than one tile, single-plane residual
     (25000, 512, 1024, "fp4", "fp4", "fp4", True, True),      # the trunk form: every lo part only as FP4 (mx_flags)
+    # K >= 1024 runs the software-pipelined stream (k_gemm_mx_pipe), K < 1024 the two-barrier kernel (k_gemm_ring_mx): the same forms again
+    (25000, 1024, 1024, "fp4", "fp4", "fp4", True, True),     # trunk form, several tiles per CU, 256-row tiles
+    (66000, 1024, 256, True, None, False, False, True),       # both corrections, 128-row tiles
+    (25000, 1280, 512, False, True, True, True, True),        # odd number of K macro-blocks, split residual and output
 ])
 def test_mx_gemm(case, cuda_device):
     """w_split = 2: main product on f16 hi parts, corrections Q4(W lo) x Q4(x hi) [+ Q4(W hi) x Q4(x lo)] on the block-scaled
@@ -498,7 +502,7 @@ def test_mx_gemm(case, cuda_device):
         assert torch.all(_unbundle(out_mx.cpu(), Mp, N, 0)[0][M:] == 0xEE)          # rows past M untouched
 
 
-@pytest.mark.parametrize("shape", [(256 * 700, 512, 512, 2), (256 * 300 + 77, 1024, 256, 1)])
+@pytest.mark.parametrize("shape", [(256 * 700, 512, 512, 2), (256 * 300 + 77, 1024, 256, 1), (256 * 500, 1024, 512, 2)])
 def test_mx_gemm_repeats_under_load(shape, cuda_device):
     """Race screen for the software-pipelined MX GEMM (k_gemm_mx_pipe: LDS slots re-filled by inline-asm LDS-DMA behind a barrier
     that sits in the middle of the MFMA stream, fragments read ahead across it): conv3-like shapes with several tiles per CU
