@@ -203,13 +203,16 @@ def test_bilinear_align_corners(case, precision, cuda_device):
     assert float(dst[:, Cc:].abs().max()) == 0.0                     # the neighbouring columns are untouched
 
 
+@pytest.mark.parametrize("layout", [0, 3])      # 3 = k_gemm_w4, the one-wave-per-SIMD experiment (16-bit, N % 256 == 0)
 @pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("case", [  # (M, K, N, residual, relu)
     (1000, 64, 128, False, True), (777, 256, 64, False, True), (2600, 128, 256, True, True), (50000, 512, 256, False, False),
     (300, 2048, 1024, True, True), (4097, 1024, 512, False, True), (65, 64, 19, False, False),
 ])
-def test_pointwise_gemm(case, precision, cuda_device):
+def test_pointwise_gemm(case, precision, layout, cuda_device):
     import torch
+    if layout == 3 and (precision == "f32" or case[2] % 256):
+        pytest.skip("k_gemm_w4 takes 16-bit operands and N % 256 == 0")
     from vision_semantic_segmentation_amd.network import OP_GEMM, AvlSegOp
     M, K, N, res, relu = case
     tdt, did, tol = _dt(precision)
@@ -236,6 +239,7 @@ def test_pointwise_gemm(case, precision, cuda_device):
     op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = 1, M, K, K, Mp
     op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = 1, M, N, N, Mp
     op.relu, op.out_f32, op.w_rows, op.ksize, op.stride, op.dil, op.groups = int(relu), int(out_f32), Np, 1, 1, 1, 1
+    op.w_layout = layout
     if res:
         rd = r.to(cuda_device)
         op.in2, op.in2_ld = rd.data_ptr(), N
