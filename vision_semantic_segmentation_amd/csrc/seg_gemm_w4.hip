@@ -134,9 +134,9 @@ __global__ void __launch_bounds__(256) k_gemm_w4(W4Args p, int mtiles) {
                 else if (W4_SCHED == 1) {        // half of the stage's DMA under the fragment-read latency at the head of the stage
                     if (feed && mi == 0) { issue_one(0); issue_one(1); issue_one(2); issue_one(3); }
                     if (feed && mi == 4) { issue_one(4); issue_one(5); issue_one(6); issue_one(7); }
-                } else {
+                } else if (W4_SCHED == 2) {
                     if (feed && (mi & 1) == 0) { issue_one(mi); issue_one(mi + 1); }
-                }
+                }                                // W4_SCHED == 3: no DMA after the prologue (timing probe: results are garbage)
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -197,6 +197,7 @@ int launch_w4_typed(const W4Args& a0, hipStream_t s) {
     } while (0)
     if (sched == 1) AVL_W4_LAUNCH(1);
     else if (sched == 2) AVL_W4_LAUNCH(2);
+    else if (sched == 3) AVL_W4_LAUNCH(3);
     else AVL_W4_LAUNCH(0);
 #undef AVL_W4_LAUNCH
     AVL_LAUNCH_CHECK();
