@@ -261,9 +261,11 @@ typedef struct avl_seg_op {
     int32_t w_layout;        /* GCONV: 0 = float [group][tap][ci][co] (direct kernel),
                                        1 = bf16 block-diagonal 32-channel windows [window][2][9][16][32] (MFMA kernel)
                                 STEM:  0 = float [7][7][3][64] (direct kernel), 1 = bf16 [4][6][16][32] (MFMA kernel)
-                                GEMM:  0 = the library picks the kernel; 3 = EXPERIMENT, not used by the network: the plain
-                                       16-bit GEMM on one wave per SIMD (k_gemm_w4: 128 x 128 wave tiles, accumulators in
-                                       AGPRs; N % 256 == 0, no split planes) -- tools/bench_gemm.py --variants 0,3        */
+                                GEMM:  0 = the library picks the kernel; 1 .. 4 force one tile configuration of the 16-bit
+                                       kernels (A/B experiments: 1 = 128 x 128 two-buffer kernel, 2 = 256 x 128 ring,
+                                       3 = 256 x 256 ring, 4 = 256 x 128 on four waves); 5 = EXPERIMENT, not used by the
+                                       network: the plain 16-bit GEMM on one wave per SIMD (k_gemm_w4: 128 x 128 wave tiles,
+                                       accumulators in AGPRs; N % 256 == 0, no split planes) -- tools/bench_gemm.py --variants 0,5 */
     int32_t w_split;         /* "mixed" precision (AVL_F16 only): 1 = `weight` holds each folded weight as an f16 pair
                                 hi = f16(w), lo = f16(w - hi), packed per 64-wide K block in the order the kernel
                                 walks it (GEMM/DWPW: [n][K/64][hi 64 | lo 64], or [hi | lo | hi] when the input is

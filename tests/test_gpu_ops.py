@@ -203,7 +203,7 @@ def test_bilinear_align_corners(case, precision, cuda_device):
     assert float(dst[:, Cc:].abs().max()) == 0.0                     # the neighbouring columns are untouched
 
 
-@pytest.mark.parametrize("layout", [0, 3])      # 3 = k_gemm_w4, the one-wave-per-SIMD experiment (16-bit, N % 256 == 0)
+@pytest.mark.parametrize("layout", [0, 5])      # 5 = k_gemm_w4, the one-wave-per-SIMD experiment (16-bit, N % 256 == 0)
 @pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("case", [  # (M, K, N, residual, relu)
     (1000, 64, 128, False, True), (777, 256, 64, False, True), (2600, 128, 256, True, True), (50000, 512, 256, False, False),
@@ -211,7 +211,7 @@ def test_bilinear_align_corners(case, precision, cuda_device):
 ])
 def test_pointwise_gemm(case, precision, layout, cuda_device):
     import torch
-    if layout == 3 and (precision == "f32" or case[2] % 256):
+    if layout == 5 and (precision == "f32" or case[2] % 256):
         pytest.skip("k_gemm_w4 takes 16-bit operands and N % 256 == 0")
     from vision_semantic_segmentation_amd.network import OP_GEMM, AvlSegOp
     M, K, N, res, relu = case

@@ -77,7 +77,7 @@ if __name__ == "__main__":
     tot = {}
     for sh in SHAPES:
         for v in [int(x) for x in a.variants.split(",")]:
-            if v == 3 and sh[3] % 256:          # k_gemm_w4 (one wave per SIMD, experiment): N % 256 == 0 only
+            if v == 5 and sh[3] % 256:          # k_gemm_w4 (one wave per SIMD, experiment): N % 256 == 0 only
                 continue
             tot[v] = tot.get(v, 0.0) + run(*sh, variant=v, reps=a.reps, check=not a.no_check, pad=a.pad)
     print("sum over shapes (ms):", {k: round(v, 4) for k, v in tot.items()})

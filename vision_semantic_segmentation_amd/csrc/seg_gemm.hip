@@ -1429,10 +1429,10 @@ int validate_gemm(const avl_seg_op& op) {
     return AVL_OK;
 }
 
-int launch_gemm_w4(const avl_seg_op& op, hipStream_t s);      // seg_gemm_w4.hip: one-wave-per-SIMD experiment (w_layout = 3)
+int launch_gemm_w4(const avl_seg_op& op, hipStream_t s);      // seg_gemm_w4.hip: one-wave-per-SIMD experiment (w_layout = 5)
 
 int launch_gemm(const avl_seg_op& op, hipStream_t s) {
-    if (op.w_layout == 3) return launch_gemm_w4(op, s);
+    if (op.w_layout == 5) return launch_gemm_w4(op, s);
     GemmArgs a;
     a.A = op.in; a.W = op.weight; a.bias = op.bias; a.R = op.in2; a.C = op.out;
     a.lda = op.in_ld; a.ldr = op.in2_ld; a.ldc = op.out_ld;

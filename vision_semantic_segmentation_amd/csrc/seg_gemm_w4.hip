@@ -6,7 +6,7 @@
 // 64 KB slots fill the LDS.  This kernel tests the other way to use the 160 KB: FOUR stages of 32 K-values (64-byte LDS rows, 16 KB
 // per operand and stage), the LDS-DMA of stage s + 3 spread evenly between the MFMAs of stage s (one instruction per eight MFMAs),
 // one barrier per stage between four waves instead of eight.  Plain GEMM only (one 16-bit plane in, one out, optional single-plane
-// residual): it is reachable through AVL_OP_GEMM with w_layout = 3 (tools/bench_gemm.py --variants 3) and is NOT used by the network.
+// residual): it is reachable through AVL_OP_GEMM with w_layout = 5 (tools/bench_gemm.py --variants 5) and is NOT used by the network.
 //
 // Layout: tile 256 x 256, waves 2 x 2, wave tile 128 rows (pixels) x 128 columns (channels) = acc[h 2][mi 8][nj 4] (256 registers).
 // The product is computed transposed as in k_gemm_ring (weights on the MFMA's row operand, permuted so that a lane ends with 16
@@ -206,7 +206,7 @@ int launch_w4_typed(const W4Args& a0, hipStream_t s) {
 
 }  // namespace
 
-// experiment entry (w_layout = 3): one 16-bit plane in / out, N % 256 == 0, K % 32 == 0, rows padded to 256
+// experiment entry (w_layout = 5): one 16-bit plane in / out, N % 256 == 0, K % 32 == 0, rows padded to 256
 int launch_gemm_w4(const avl_seg_op& op, hipStream_t s) {
     AVL_REQUIRE(is_half(op.dtype) && !op.w_split && !op.in_lo && !op.in2_lo && !op.out_lo && !op.out_f32 && !op.in3, "k_gemm_w4: plain 16-bit GEMM only");
     AVL_REQUIRE(op.out_c % 256 == 0 && op.in_c % 32 == 0 && op.w_rows >= op.out_c, "k_gemm_w4: N %% 256, K %% 32");
