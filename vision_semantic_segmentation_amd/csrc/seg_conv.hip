@@ -483,14 +483,26 @@ __global__ void __launch_bounds__(kThreads) k_gap_final(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------ gemv
-// out[n] = act(sum_k w[n][k] * in[k] + bias[n]); fp32; one wave per output.
+// out[n] = act(sum_k w[n][k] * in[k] + bias[n]); fp32; one wave per output.  A lane takes 16-byte pieces of the row (K % 4 == 0:
+// four independent partial sums, all of a row's loads in flight at once -- with one float per lane and iteration the K = 2048
+// product of the ASPP image-pooling branch was a chain of 32 dependent load + FMA steps, 18 us for half a MFLOP).
 __global__ void __launch_bounds__(kThreads) k_gemv(const float* __restrict__ in, const float* __restrict__ w,
                                                   const float* __restrict__ bias, float* __restrict__ out, int N, int K, int relu) {
     const int n = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (n >= N) return;
-    float s = 0.f;
-    for (int k = lane; k < K; k += 64) s = fmaf(w[(long long)n * K + k], in[k], s);
+    const float* wr = w + (long long)n * K;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(wr) & 15) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+#pragma unroll 8
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(wr + k), b = *reinterpret_cast<const float4*>(in + k);
+            s0 = fmaf(a.x, b.x, s0); s1 = fmaf(a.y, b.y, s1); s2 = fmaf(a.z, b.z, s2); s3 = fmaf(a.w, b.w, s3);
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) s0 = fmaf(wr[k], in[k], s0);
+    }
+    float s = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if (lane == 0) {
