@@ -387,6 +387,30 @@ def test_mixed_logits_without_the_mx_grouped_conv(state, cuda_device):
     assert rel <= 1e-3
 
 
+def test_mixed_logits_with_layer1_lo_planes(state, cuda_device):
+    """MODEL.MIXED_LAYER1_LO = True (every block of layer1 keeps a lo plane of its output; the default keeps it for the last block
+    only): more HBM traffic, a smaller error -- through the cfg switch, and the plan really differs."""
+    import numpy as np
+    from oracle import network_oracle as no
+    from test_gpu_seg import _cfg
+    from vision_semantic_segmentation_amd import SemanticSegmentation
+    cfg = _cfg("mixed")
+    assert cfg.MODEL.MIXED_LAYER1_LO is False
+    img = np.random.default_rng(0).integers(0, 256, size=(320, 416, 3), dtype=np.uint8)
+    ref = no.forward_logits(state, img)[0]
+    errs, los = [], []
+    for flag in (False, True):
+        cfg.MODEL.MIXED_LAYER1_LO = flag
+        seg = SemanticSegmentation(cfg, device=cuda_device, state_dict=state)
+        got = seg.logits(img).cpu()
+        net = seg.net_for(320, 416)
+        los.append(sum(1 for n, op in zip(net.op_names, net.ops) if n.startswith("backbone.layer1.") and n.endswith("conv3") and op.out_lo))
+        errs.append(float((got - ref).abs().max() / ref.abs().max()))
+    print("mixed 320x416: layer1 lo planes off / on: max rel err %.3e / %.3e" % tuple(errs))
+    assert los == [1, 3]                       # conv3 outputs of layer1 that carry a lo plane
+    assert errs[0] <= 9e-4 and errs[1] <= errs[0]
+
+
 def _bundle(hi64, lo64, rows_pad):
     """MX bundle [Q4(hi) | scales | Q4(lo) | scales] of a split tensor, rows padded with zeros"""
     import torch

@@ -16,6 +16,8 @@ cases = [(0, 1, 480, 640), (0, 2, 480, 640), (1, 0, 480, 640), (2, 3, 480, 640),
 opts = {kv.split("=")[0]: bool(int(kv.split("=")[1])) for kv in (sys.argv[1].split(",") if len(sys.argv) > 1 and sys.argv[1] != "-" else []) if kv}
 if len(sys.argv) > 2 and sys.argv[2] == "wide":
     cases = [(ws, 10 + 3 * ws + i, 480, 640) for ws in range(4) for i in range(4)]
+if os.environ.get("SWEEP_SHORT"):      # three cases: the two worst 480 x 640 draws and the worst 1080p one
+    cases = [(0, 1, 480, 640), (2, 3, 480, 640), (2, 7, 1080, 1920)]
 print("mixed options:", opts, flush=True)
 for wseed, iseed, h, w in cases:
     state = random_state_dict(wseed)

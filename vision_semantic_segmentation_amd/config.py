@@ -102,6 +102,8 @@ def get_network_cfg_defaults():
                                         # -5 % frames/s; False was the round-2 default, whose error passed 1e-3 on one weights draw in four (profiles/r02/seed_sweep.log)
     C.MODEL.MIXED_TRUNK_FP4 = True      # "mixed" only: keep the lo part of the residual trunk / 3x3 outputs as FP4 only (False: f16 lo planes, 12 % slower, -0..14 % error)
     C.MODEL.MIXED_CONV2_SPLIT = True    # "mixed" only: keep every bottleneck's 3x3 output as hi + lo (conv3 corrects for both parts)
+    C.MODEL.MIXED_LAYER1_LO = False     # "mixed" only: True = layer1's first two blocks keep a lo plane of their output as well (the last block always does):
+                                        # -10..-30 % logits error (worst draw 7.3e-4 instead of 8.2e-4 at 1080p) for +0.4 GB of HBM traffic per frame (-2.5 % frames/s)
     C.MODEL.SEED = 0               # seed of the random weights used when MODEL.WEIGHT == ""
     C.MODEL.HIP_GRAPH = True       # replay the ~90-kernel plan as one hipGraph launch per frame
     return C

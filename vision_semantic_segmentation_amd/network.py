@@ -411,7 +411,7 @@ class SegNet(object):
     native plan.  ``forward(image_u8_cuda)`` runs it; ``labels`` / ``logits`` are views of its outputs."""
 
     ROW_PAD = 256        # GEMM tiles read whole 128/256-row tiles
-    MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx", "dw_exact")    # keyword switches of the "mixed" mode
+    MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx", "dw_exact", "layer1_lo")    # keyword switches of the "mixed" mode
 
     def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8, fuse_dwpw=True, raw_frame=None,
                  **mixed_opts):
@@ -442,6 +442,10 @@ class SegNet(object):
         self.mixed_trunk_fp4 = mixed_opts.get("trunk_fp4", True)
         self.mixed_fuse_ds = mixed_opts.get("fuse_ds", True)     # stride-1 downsample folded into conv3 (second input along K)
         self.mixed_dw_exact = mixed_opts.get("dw_exact", True)    # fused depthwise+pointwise (ASPP) with split depthwise weights and a split depthwise result (k_dwpw_x)
+        # layer1_lo = False (default): the first two blocks of layer1 write a SINGLE f16 trunk plane (the last one keeps hi + lo: the
+        # decoder's low-level branch and layer2 read it).  layer1's GEMMs are HBM-bound (K = 128 / 256 at 129 600 pixels): the lo planes
+        # are 0.4 GB of the frame's traffic = 2.5 % of its time, for -10...-30 % logits error (8.2e-4 -> 7.3e-4 on the worst draw)
+        self.mixed_layer1_lo = mixed_opts.get("layer1_lo", False)
         self.mixed_gconv_mx = mixed_opts.get("gconv_mx", True)   # grouped conv with FP4 corrections for its weights AND for conv1's output (-10..-30 % logits error, -5 % frames/s)
         self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "mixed": torch.float16}[precision]
         self.avl_dtype = {"bf16": _lib.AVL_BF16, "f16": _lib.AVL_F16, "f32": _lib.AVL_F32, "mixed": _lib.AVL_F16}[precision]
@@ -674,6 +678,7 @@ class SegNet(object):
                 stride = 1
             for bi in range(nblocks):
                 p = "backbone.layer%d.%d" % (li, bi)
+                trunk_lo = self.mixed_layer1_lo or li != 1 or bi == nblocks - 1      # does this block's output keep its lo plane
                 s = stride if bi == 0 else 1
                 d = previous_dilation if bi == 0 else dilation
                 ohw = ((hw[0] + 2 * d - 2 * d - 1) // s + 1, (hw[1] + 2 * d - 2 * d - 1) // s + 1)
@@ -733,7 +738,7 @@ class SegNet(object):
                         if keep_lo:
                             self._spatial(p + ".downsample.sub[lo]", OP_SUBSAMPLE, x.lo, hw, cin, sub.lo, ohw, cin, stride=s)
                         src = sub
-                    idn = self._act(ohw[0] * ohw[1], cout, split=self.mixed)
+                    idn = self._act(ohw[0] * ohw[1], cout, split=self.mixed and trunk_lo)
                     self._gemm(p + ".downsample", src, ohw, cin, w, b, idn, relu=False, read_lo=self.mixed_conv1_split)
                     if s != 1:
                         self._release(sub)
@@ -745,7 +750,7 @@ class SegNet(object):
                 # through conv3's epilogue, which is what bounds it: the 10 % error of FP4 hits a term that is 2^-11 of the sum)
                 trunk_fp4 = (self.mixed_mx and self.mixed_trunk_fp4 and t2.mx is not None and t2.mx_valid and width % 256 == 0
                              and cout % 256 == 0 and t2.hi.shape[1] == width)
-                y = self._act(ohw[0] * ohw[1], cout, split=self.mixed, mx=True, lo_fp4=trunk_fp4)
+                y = self._act(ohw[0] * ohw[1], cout, split=self.mixed and trunk_lo, mx=True, lo_fp4=trunk_fp4)
                 if fuse_ds:
                     wd_, bd_ = fold_bn(st, p + ".downsample.0.weight", p + ".downsample.1")
                     self._gemm(p + ".conv3+downsample", t2, ohw, width, w, b, y, relu=True, src2=x, w2=wd_.reshape(cout, cin), b2=bd_)

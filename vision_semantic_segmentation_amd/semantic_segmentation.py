@@ -50,7 +50,8 @@ class SemanticSegmentation(object):
                          raw_frame=raw_frame,
                          conv2_split=bool(getattr(self.cfg.MODEL, "MIXED_CONV2_SPLIT", True)),
                          gconv_mx=bool(getattr(self.cfg.MODEL, "MIXED_GCONV_MX", True)),
-                         trunk_fp4=bool(getattr(self.cfg.MODEL, "MIXED_TRUNK_FP4", True)))
+                         trunk_fp4=bool(getattr(self.cfg.MODEL, "MIXED_TRUNK_FP4", True)),
+                         layer1_lo=bool(getattr(self.cfg.MODEL, "MIXED_LAYER1_LO", False)))
             if getattr(self.cfg.MODEL, "HIP_GRAPH", True):
                 net.capture_graph()
             self._nets[key] = net
