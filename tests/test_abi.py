@@ -52,27 +52,72 @@ def test_missing_library_fails_loudly(monkeypatch):
         _lib.lib()
 
 
-def test_hand_counted_kernels_do_not_spill(tmp_path):
-    """k_gemm_ring waits for its LDS-DMA with hand-counted `s_waitcnt vmcnt(N)`.  A register spill adds scratch loads
-    and stores to the same in-order counter and silently breaks that arithmetic, so the build must keep it spill-free
-    (checked on the compiler's own resource metadata); k_dwpw sits at ~220 VGPRs and is held to the same bar."""
-    import shutil
+SO = os.path.join(ROOT, "vision_semantic_segmentation_amd", "libavl_hip.so")
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def _notes():
+    import sys
+    if not os.path.exists(SO):
+        pytest.fail("libavl_hip.so is not built: run __graft_entry__.build()")
+    if not os.path.exists(os.path.join(LLVM_BIN, "llvm-readelf")):
+        pytest.skip("ROCm LLVM tools not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_notes
+    return kernel_notes
+
+
+def test_no_kernel_of_the_built_library_spills_or_owns_scratch():
+    """The MX / ring GEMMs, the grouped conv and the fused depthwise kernels wait for their LDS-DMA with hand-counted
+    `s_waitcnt vmcnt(N)`.  A VGPR spill puts scratch loads and stores on the same in-order counter (and hipcc drains `vmcnt(0)`
+    behind a reload, i.e. every DMA burst in flight), so the SHIPPED code objects must be scratch-free: read from the notes of the
+    built libavl_hip.so (`llvm-readelf --notes` on its unbundled gfx950 code objects), not from a recompilation with other flags.
+    VERDICT r3: k_gemm_mx_pipe<1,8,0,0> spilled 6 VGPRs (28 bytes of scratch) and the old test never looked at it."""
+    kn = _notes()
+    notes = kn.kernel_notes(SO)
+    assert len(notes) > 50
+    for family in ("k_gemm_mx_pipe", "k_gemm_ring_mx", "k_gemm_ring", "k_gconv_mfma", "k_dwpw", "k_dwpw_x", "k_stem_mfma", "k_fused_vote"):
+        assert any(family in n for n in notes), "no %s kernel in the built library" % family
+    dirty = {n: v for n, v in notes.items() if v["vgpr_spill_count"] or v["private_segment_fixed_size"]}
+    assert not dirty, "kernels with VGPR spills / scratch in libavl_hip.so: %s" % dirty
+    for n, v in notes.items():
+        assert v["vgpr_count"] + 0 <= 512 and v["agpr_count"] <= 256
+
+
+def test_mx_pipe_stream_holds_no_scalar_loads_and_no_scratch():
+    """Inside the software-pipelined stream of k_gemm_mx_pipe (first to last MFMA of the kernel: K loops, tile switches and
+    epilogues) there must be no kernarg / scalar load (SMEM completes out of order on lgkmcnt: hipcc would put `lgkmcnt(0)` in
+    front of LDS fragment uses) and no scratch access (vmcnt).  Checked on the disassembly of the built library."""
+    kn = _notes()
+    dis = kn.disassembly(SO, "k_gemm_mx_pipe")
+    assert len(dis) >= 4
+    for sym, ins in dis.items():
+        mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma")]
+        assert len(mf) >= 64, sym
+        stream = ins[mf[0]:mf[-1]]
+        bad = [l for l in stream if l.startswith(("s_load", "s_buffer_load", "scratch_"))]
+        assert not bad, "%s: %s" % (sym, bad[:4])
+        assert not any(l.startswith("scratch_") for l in ins), sym
+        # the two hand-counted events are there (a compiler change that drops or rewrites the asm would show here)
+        assert any(l.startswith("s_waitcnt vmcnt(4)") for l in stream) or "Li4ELi" in sym, sym
+
+
+def test_release_library_reads_no_environment_and_holds_no_experiment_kernels():
+    """VERDICT r3 / ADVICE r3: timing probes (results are garbage by design), A/B switches and the k_gemm_w4 experiment live in
+    the experiments build only (`make experiments`, -DAVL_EXPERIMENTS -> libavl_hip_exp.so): the release library must not even
+    import getenv, and must not contain a probe instantiation of the MX GEMM or the experiment kernel."""
     import subprocess
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("hipcc not available")
-    root = os.path.join(os.path.dirname(__file__), "..")
-    csrc = os.path.join(root, "vision_semantic_segmentation_amd", "csrc")
-    for src, kernels in (("seg_dwpw.hip", ("k_dwpw",)), ("seg_gemm.hip", ("k_gemm_ring",))):
-        out = os.path.join(str(tmp_path), src + ".s")
-        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(root, "include"), "-I" + csrc,
-                        "-S", "--cuda-device-only", "-o", out, os.path.join(csrc, src)], check=True, capture_output=True)
-        name, seen = None, 0
-        for line in open(out):
-            line = line.strip()
-            if line.startswith(".name:"):
-                name = line.split()[-1]
-            elif line.startswith(".vgpr_spill_count:") and name and any(k in name for k in kernels):
-                seen += 1
-                assert int(line.split()[-1]) == 0, "%s spills %s VGPRs" % (name, line.split()[-1])
-        assert seen > 0, "no %s kernel found in %s" % (kernels, src)
+    kn = _notes()
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", SO], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    strings = subprocess.run(["strings", SO], capture_output=True, text=True, check=True).stdout
+    for name in ("AVL_MX_PROBE", "AVL_GEMM_PROBE", "AVL_SWEEP_EXP", "AVL_GC_PROBE", "AVL_MX_PIPE", "AVL_MX_LATE", "AVL_MX_TILE",
+                 "AVL_MX_STAGGER", "AVL_APPLY_MODE", "AVL_MASK_MODE", "AVL_GCONV_TH", "AVL_GC_DEPHASE", "AVL_DW_NCHUNK", "AVL_GEMM_DEEP"):
+        assert name not in strings, name
+    names = list(kn.kernel_notes(SO))
+    assert not any("k_gemm_w4" in n for n in names)
+    import re as _re
+    for n in names:
+        m = _re.search(r"k_gemm_mx_pipe<(\d+), (\d+), (\d+), (\d+)>", n)
+        if m:
+            assert m.group(4) == "0", "probe instantiation in the release library: %s" % n

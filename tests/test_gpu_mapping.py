@@ -335,6 +335,18 @@ def test_pointcloud2_unpack_on_device(cuda_device):
     assert torch.equal(torch.nan_to_num(d2), torch.nan_to_num(dev_pts[:100])) and int(c2.item()) == int((~bad[:100]).sum())
     d0, c0 = a.unpack_pointcloud2_device(_pointcloud2([]))
     assert d0.shape[0] == 0 and int(c0.item()) == 0
+    # an explicit (side) stream, alternating with the current one: zero-fill, upload and kernel all go on the stream handed in
+    # (ADVICE r3), the shared staging buffers are ordered across the two streams by events
+    side = torch.cuda.Stream(device=cuda_device)
+    for rep in range(6):
+        if rep % 2 == 0:
+            d3, c3 = a.unpack_pointcloud2_device(msg, stream=side.cuda_stream)
+            side.synchronize()
+        else:
+            d3, c3 = a.unpack_pointcloud2_device(msg2)
+        want_n, want = (30000, dev_pts) if rep % 2 == 0 else (100, dev_pts[:100])
+        assert d3.shape[0] == want_n and int(c3.item()) == int((~bad[:want_n]).sum())
+        assert torch.equal(torch.nan_to_num(d3), torch.nan_to_num(want))
 
 
 @pytest.mark.parametrize("match", ["reference", "colour"])

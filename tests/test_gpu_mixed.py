@@ -526,28 +526,42 @@ def test_mx_gemm(case, cuda_device):
         assert torch.all(_unbundle(out_mx.cpu(), Mp, N, 0)[0][M:] == 0xEE)          # rows past M untouched
 
 
-@pytest.mark.parametrize("shape", [(256 * 700, 512, 512, 2), (256 * 300 + 77, 1024, 256, 1), (256 * 500, 1024, 512, 2)])
+@pytest.mark.parametrize("shape", [  # (M, K, N, correction passes, K of a second input appended along K or 0)
+    (256 * 700, 1024, 512, 2, 0),            # 256-row tiles, 5.5 tiles per CU
+    (256 * 300 + 77, 1024, 256, 1, 0),       # 128-row tiles (k_gemm_mx_pipe<., 4, ...>), weights-only correction, ragged last tile
+    (256 * 500, 1024, 512, 2, 0),
+    (256 * 400, 512, 512, 2, 1024),          # conv3 + downsample form: the stream switches inputs at K macro-block 2 of 6 (set_input)
+    (256 * 300, 1024, 256, 2, 512),          # the same on 128-row tiles
+    (256 * 700, 512, 512, 2, 0),             # K < 1024: the two-barrier kernel k_gemm_ring_mx (kept: it runs the short-K layers)
+])
 def test_mx_gemm_repeats_under_load(shape, cuda_device):
-    """Race screen for the software-pipelined MX GEMM (k_gemm_mx_pipe: LDS slots re-filled by inline-asm LDS-DMA behind a barrier
-    that sits in the middle of the MFMA stream, fragments read ahead across it): conv3-like shapes with several tiles per CU
-    (256-row tiles and, second case, 128-row tiles), both correction passes, FP4 residual and output, launched back to back
-    with copies in between, must give the same bytes every time -- and the first launch is checked against float64."""
+    """Race screen for the software-pipelined MX GEMM (k_gemm_mx_pipe, every case with K >= 1024: LDS slots re-filled by inline-asm
+    LDS-DMA behind a barrier that sits in the middle of the MFMA stream, fragments read ahead across it): conv3-like shapes with
+    several tiles per CU, 256- and 128-row tiles, one and two correction passes, one and two inputs along K (no unit
+    case used to drive the pipe kernel's input switch), FP4 residual and output, launched back to back with copies in between,
+    must give the same bytes every time -- and the first launch is checked against float64."""
     import torch
     from vision_semantic_segmentation_amd import _lib
     from vision_semantic_segmentation_amd.network import (AVL_MX_IN_LO, AVL_MX_OUT_LO, AVL_MX_RES_LO, OP_GEMM, AvlSegOp, mx_bundle_bytes,
                                                           mx_dequant_fp4, mx_quant_fp4, pack_mx_weights)
-    M, K, N, nmx = shape
+    M, K, N, nmx, K2 = shape
     Mp = (M + 255) // 256 * 256
     g = torch.Generator().manual_seed(11)
     a_hi = torch.randn((Mp, K), generator=g).to(torch.float16)
     a_lo = (torch.randn((Mp, K), generator=g) * 2 ** -11).to(torch.float16)
+    if K2:
+        assert nmx == 2
+        b_hi = torch.randn((Mp, K2), generator=g).to(torch.float16)
+        b_lo = (torch.randn((Mp, K2), generator=g) * 2 ** -11).to(torch.float16)
     r_hi = torch.randn((Mp, N), generator=g).to(torch.float16)
     r_lo = (torch.randn((Mp, N), generator=g) * 2 ** -11).to(torch.float16)
-    w64 = torch.randn((N, K), generator=g, dtype=torch.float64) / K ** 0.5
+    w64 = torch.randn((N, K + K2), generator=g, dtype=torch.float64) / (K + K2) ** 0.5
     w_hi16, wbundle = pack_mx_weights(w64)
     bd = torch.randn(N, generator=g).to(cuda_device)
     a_d, r_d = a_hi.to(cuda_device), r_hi.to(cuda_device)
     in_mx, r_mx = _bundle(a_hi, a_lo, Mp).to(cuda_device), _bundle(r_hi, r_lo, Mp).to(cuda_device)
+    if K2:
+        b_d, in3_mx = b_hi.to(cuda_device), _bundle(b_hi, b_lo, Mp).to(cuda_device)
     wd, wmx = w_hi16.to(cuda_device), wbundle.to(cuda_device)
     out = torch.zeros((Mp, N), dtype=torch.float16, device=cuda_device)
     out_mx = torch.zeros(2 * mx_bundle_bytes(Mp, N), dtype=torch.uint8, device=cuda_device)
@@ -560,6 +574,8 @@ def test_mx_gemm_repeats_under_load(shape, cuda_device):
     op.w_split, op.w_mx, op.in_mx, op.out_mx = 2, wmx.data_ptr(), in_mx.data_ptr(), out_mx.data_ptr()
     op.in2, op.in2_ld, op.in2_mx = r_d.data_ptr(), N, r_mx.data_ptr()
     op.mx_flags = (AVL_MX_IN_LO if nmx == 2 else 0) | AVL_MX_RES_LO | AVL_MX_OUT_LO
+    if K2:
+        op.in3, op.in3_mx, op.in3_c, op.in3_ld = b_d.data_ptr(), in3_mx.data_ptr(), K2, K2
     plan = C.c_void_p()
     _lib.check(_lib.lib().avl_seg_plan_create((AvlSegOp * 1)(op), 1, C.byref(plan)), "avl_seg_plan_create")
     try:
@@ -572,10 +588,14 @@ def test_mx_gemm_repeats_under_load(shape, cuda_device):
         w_hi = w64.to(torch.float16)
         w_lo = (w64 - w_hi.double()).to(torch.float16)
         for lo_, hi_ in ((0, 4096), (Mp - 256, M)):
-            xa, xl = a_hi[lo_:Mp if hi_ == M else hi_], a_lo[lo_:Mp if hi_ == M else hi_]
-            want = xa.double() @ w_hi.double().t() + deq(xa) @ deq(w_lo).t() + bd.cpu().double()
+            hi_p = Mp if hi_ == M else hi_
+            xa, xl = a_hi[lo_:hi_p], a_lo[lo_:hi_p]
+            want = xa.double() @ w_hi[:, :K].double().t() + deq(xa) @ deq(w_lo[:, :K]).t() + bd.cpu().double()
             if nmx == 2:
-                want = want + deq(xl) @ deq(w_hi).t()
+                want = want + deq(xl) @ deq(w_hi[:, :K]).t()
+            if K2:
+                xb, xbl = b_hi[lo_:hi_p], b_lo[lo_:hi_p]
+                want = want + xb.double() @ w_hi[:, K:].double().t() + deq(xb) @ deq(w_lo[:, K:]).t() + deq(xbl) @ deq(w_hi[:, K:]).t()
             rr = r_hi[lo_:lo_ + want.shape[0]].double() + deq(r_lo[lo_:lo_ + want.shape[0]])
             want = torch.relu(want + rr)[:hi_ - lo_]
             got = ref[lo_:hi_].cpu().double()
@@ -626,14 +646,16 @@ def test_grouped_conv_writes_the_mx_bundle(case, cuda_device):
         assert torch.equal(s_dev[:, :M], s_ref) and torch.equal(v_dev[:M], mx_dequant_fp4(q_ref, s_ref)), "plane %d" % half
 
 
-def test_mx_gemm_with_a_second_input_along_k(cuda_device):
+@pytest.mark.parametrize("ks", [(25000, 512, 256, 1024), (25000, 512, 1024, 1024), (40000, 1024, 512, 256), (25000, 256, 1024, 512)])
+def test_mx_gemm_with_a_second_input_along_k(ks, cuda_device):
     """conv3 + stride-1 downsample as ONE MX GEMM: out = relu(W3 . t2 + Wd . x + b3 + bd), both inputs with FP4-only lo parts
-    (in3 / in3_mx of include/avl_hip.h).  Reference: float64 on the operands the kernel is given."""
+    (in3 / in3_mx of include/avl_hip.h).  Reference: float64 on the operands the kernel is given.  K1 + K2 < 1024 runs
+    k_gemm_ring_mx, the others the software-pipelined k_gemm_mx_pipe (256-row tiles; third case: 128-row tiles)."""
     import torch
     from vision_semantic_segmentation_amd import _lib
     from vision_semantic_segmentation_amd.network import (AVL_MX_IN_LO, AVL_MX_OUT_LO, OP_GEMM, AvlSegOp, mx_bundle_bytes, mx_dequant_fp4,
                                                           mx_quant_fp4, pack_mx_weights)
-    M, K1, K2, N = 25000, 512, 256, 1024
+    M, K1, K2, N = ks
     g = torch.Generator().manual_seed(7)
     Mp = (M + 255) // 256 * 256
     deq = lambda t: mx_dequant_fp4(*mx_quant_fp4(t.double()))            # noqa: E731

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of the MX GEMM kernels on one box: per-op profile of the mixed plan with the round-2 kernel (AVL_MX_PIPE=0) and the
 # software-pipelined one (AVL_MX_PIPE=1; AVL_MX_LATE picks the step at which waves 0-3 issue their DMAs).
+. tools/use_experiments_lib.sh
 set -o pipefail
 OUT=${1:-gpurun_out/r3}
 mkdir -p $OUT

@@ -3,6 +3,7 @@
 # 2 LDS reads + MFMA (no DMA), 3 DMA + LDS reads (no MFMA); AVL_ZERO=1: all-zero activations (the chip holds a higher clock on
 # trivial operands: MI355X_MICROARCH.md, DVFS give-back).  bf16 one-plane kernel on the network's GEMM shapes.
 #   gpurun -- 'bash tools/gemm_probe.sh'
+. tools/use_experiments_lib.sh
 mkdir -p gpurun_out/probe
 for z in "" 1; do
 for p in 0 1 2 3; do

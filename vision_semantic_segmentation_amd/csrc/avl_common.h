@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "avl_hip.h"
@@ -15,6 +16,20 @@ int set_error(int code, const char* fmt, ...);
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace avl
+
+// Experiment switches (A/B schedules, timing probes whose results may be garbage).  The RELEASE library reads no environment
+// variable at all: AVL_EXP_INT / AVL_EXP_STR fold to their defaults and the probe template instantiations are not compiled.
+// `make experiments` builds libavl_hip_exp.so with -DAVL_EXPERIMENTS, which the tools/ scripts load through AVL_HIP_LIB
+// (Python side); only there do the AVL_* variables exist.  tests/test_abi.py asserts that the release build holds no "AVL_" string.
+#ifdef AVL_EXPERIMENTS
+constexpr bool kStamps = true;          // in-kernel s_memtime stamp code is compiled (it runs only where a probe hands in a buffer)
+#define AVL_EXP_INT(name, dflt) ([] { static const int v = getenv(name) ? atoi(getenv(name)) : (dflt); return v; }())
+#define AVL_EXP_STR(name) ([] { static const char* v = getenv(name); return v; }())
+#else
+constexpr bool kStamps = false;
+#define AVL_EXP_INT(name, dflt) (dflt)
+#define AVL_EXP_STR(name) (static_cast<const char*>(nullptr))
+#endif
 
 #define AVL_REQUIRE(cond, ...)                                         \
     do {                                                               \

@@ -189,7 +189,7 @@ int launch_w4_typed(const W4Args& a0, hipStream_t s) {
     a.ntiles = a.N / 256;
     const int mtiles = (a.M + 255) / 256;
     const int total = mtiles * a.ntiles;
-    static const int sched = getenv("AVL_W4_SCHED") ? atoi(getenv("AVL_W4_SCHED")) : 0;     // where in a stage the DMA instructions go
+    const int sched = AVL_EXP_INT("AVL_W4_SCHED", 0);     // where in a stage the DMA instructions go
 #define AVL_W4_LAUNCH(S)                                                                                                            \
     do {                                                                                                                            \
         AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_w4<H, S>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \

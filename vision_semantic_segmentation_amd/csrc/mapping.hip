@@ -418,7 +418,9 @@ __global__ void __launch_bounds__(kBlock) k_grid_apply_lists(MapT* __restrict__ 
                                                              unsigned char* __restrict__ mask, const int* __restrict__ touched,
                                                              int* __restrict__ counter, int cap, int wgs_per_list) {
     const int k = blockIdx.x % kLists, j = blockIdx.x / kLists;
-    const int n = counter[kListBase + k];
+    // the append drops entries past cap but its cursor still advances (k_vote_append): clamp here as well, or a stale / overrun
+    // cursor would walk into the next list
+    const int n = min(counter[kListBase + k], cap);
     const int* list = touched + (long long)k * cap;
     for (int e = j * kBlock + threadIdx.x; e < n; e += wgs_per_list * kBlock) {
         const int cell = list[e];
@@ -499,7 +501,9 @@ __global__ void __launch_bounds__(kBlock) k_grid_sweep_bytes(MapT* __restrict__ 
                 mine += __builtin_popcount(t & 0x01010101u);
             }
         }
+#ifdef AVL_EXPERIMENTS
         if (exp & 2) mine = 0;
+#endif
         const int lane = threadIdx.x & 63;
         int incl = mine;
 #pragma unroll
@@ -534,7 +538,11 @@ __global__ void __launch_bounds__(kBlock) k_grid_sweep_bytes(MapT* __restrict__ 
             if ((v[u].x | v[u].y | v[u].z | v[u].w) != 0u)
                 *reinterpret_cast<uint4*>(mask + base + (u * kBlock + threadIdx.x) * 16) = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
+#ifdef AVL_EXPERIMENTS
         const int n = (exp & 1) ? 0 : count;
+#else
+        const int n = count;
+#endif
         for (int k = threadIdx.x; k < n; k += kBlock) {
             const unsigned e = list[k];
             const unsigned m = e & 0xffu;
@@ -742,7 +750,7 @@ int launch_sweep_bytes(const avl_grid* g, const double* cm_host, unsigned bonus,
     const long long rounds = (ncell + kSweepCells - 1) / kSweepCells;
     const unsigned blocks = (unsigned)(rounds < 2048 ? rounds : 2048);
     unsigned char* mask = reinterpret_cast<unsigned char*>(g->cell_mask);
-    static const int exp = getenv("AVL_SWEEP_EXP") ? atoi(getenv("AVL_SWEEP_EXP")) : 0;      // timing experiments only
+    const int exp = AVL_EXP_INT("AVL_SWEEP_EXP", 0);      // timing experiments only (experiments build; 0 in the release library)
     if (g->map_dtype == AVL_F64)
         hipLaunchKernelGGL(k_grid_sweep_bytes<double>, dim3(blocks), dim3(kBlock), 0, s, static_cast<double*>(g->map), g->C, bonus, cm, mask, ncell, exp);
     else
@@ -753,7 +761,7 @@ int launch_sweep_bytes(const avl_grid* g, const double* cm_host, unsigned bonus,
 
 // byte mask usable: class bits + bonus bits fit a byte, whole 16-byte vectors, aligned scratch
 bool byte_mask_ok(const avl_grid* g, unsigned bonus) {
-    static const char* mode = getenv("AVL_MASK_MODE");          // "32": keep the 32-bit mask (experiments)
+    const char* mode = AVL_EXP_STR("AVL_MASK_MODE");          // "32": keep the 32-bit mask (experiments build only)
     if (mode && mode[0] == '3') return false;
     const long long cells = (long long)g->Hm * g->Wm;
     return g->C + __builtin_popcount(bonus) <= 8 && cells % 16 == 0 && (reinterpret_cast<uintptr_t>(g->cell_mask) & 15) == 0;
@@ -775,7 +783,7 @@ ListGeom list_geom(int n) {
 // measured 17 vs 22 us per frame at 120 k points on 4 M cells (config C), 54 vs 38 us at 1 M points on 16 M cells (config E).
 // AVL_APPLY_MODE=plist forces it (experiments).
 bool use_lists(const avl_grid* g, int n, unsigned bonus) {
-    static const char* mode = getenv("AVL_APPLY_MODE");
+    const char* mode = AVL_EXP_STR("AVL_APPLY_MODE");
     if (g->counter_len < kListBase + 2 * kLists || !byte_mask_ok(g, bonus)) return false;
     if ((long long)list_geom(n).cap * kLists > g->touched_cap) return false;
     if (mode && mode[0] == 'p') return true;
@@ -801,7 +809,7 @@ int launch_apply_lists(const avl_grid* g, const double* cm_host, unsigned bonus,
 // list (sparse) vs sweep (dense) apply: the sweep reads Hm*Wm*4 bytes whatever the cloud; the list costs a
 // returning atomic + an append per first touch.  AVL_APPLY_MODE=list|scan overrides (experiments).
 bool use_scan(const avl_grid* g, int n, unsigned bonus) {
-    static const char* mode = getenv("AVL_APPLY_MODE");
+    const char* mode = AVL_EXP_STR("AVL_APPLY_MODE");
     const long long cells = (long long)g->Hm * g->Wm;
     if (cells % 4 != 0 || (reinterpret_cast<uintptr_t>(g->cell_mask) & 15)) return false;
     if (mode && mode[0] == 'l') return false;

@@ -601,7 +601,7 @@ int launch_typed(const avl_seg_op& op, hipStream_t s) {
             const int chunks = op.in_c / 8;
             // channel lanes: at most 64 chunks (1 KB of a pixel) per workgroup, so that the rows a workgroup re-reads
             // two grid rows later (2 x gw x 512 B) are still in its XCD's L2 with ~1000 workgroups in flight
-            static const int max_chunk = [] { const char* e = getenv("AVL_DW_NCHUNK"); return e ? atoi(e) : 64; }();
+            const int max_chunk = AVL_EXP_INT("AVL_DW_NCHUNK", 64);
             g.nchunk = chunks < max_chunk ? chunks : max_chunk;
             while (chunks % g.nchunk) --g.nchunk;      // lanes beyond nchunk x cl idle (C = 304: 19 x 13 of 256)
             g.cl = kThreads / g.nchunk;

@@ -252,14 +252,14 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
     };
     for (; sp < p.nsp; sp += p.nslots, buf ^= 1) {
         unsigned long long t0 = 0, t1 = 0;
-        if (p.dbg) t0 = stamp();
+        if (kStamps && p.dbg) t0 = stamp();
         // The two waves of a SIMD (w and w + 4) stage the next tile at DIFFERENT points: waves 0-3 in front of their MFMA phase,
         // waves 4-7 in the middle of theirs -- the staging is ~40 vector instructions per DMA instruction (pixel -> clamped source
         // address), so one wave of the SIMD computes addresses while the other one's MFMAs run.
         const bool late_stage = NJ >= 2 && wave >= 4 && p.dephase;
         oob = 0u;
         if (!late_stage && sp + p.nslots < p.nsp) oob = stage(sp + p.nslots, buf ^ 1);
-        if (p.dbg) { t1 = stamp(); tsum[0] += t1 - t0; t0 = t1; }
+        if (kStamps && p.dbg) { t1 = stamp(); tsum[0] += t1 - t0; t0 = t1; }
         const char* tile = lds + buf * p.tile_bytes;
         f32x4 acc[NJ][2];
 #pragma unroll
@@ -334,10 +334,10 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
             acc[j][0] = acc0; acc[j][1] = acc1;
             __builtin_amdgcn_sched_barrier(0);      // keep the next sub-tile's nine fragments out of this one's registers
         }
-        if (p.dbg) { t1 = stamp(); tsum[1] += t1 - t0; t0 = t1; }
+        if (kStamps && p.dbg) { t1 = stamp(); tsum[1] += t1 - t0; t0 = t1; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         zero_oob(oob, buf ^ 1);
-        if (p.dbg) { t1 = stamp(); tsum[2] += t1 - t0; t0 = t1; }
+        if (kStamps && p.dbg) { t1 = stamp(); tsum[2] += t1 - t0; t0 = t1; }
 
         const int tx = sp % p.tiles_x, r1 = sp / p.tiles_x;
         const int ty = r1 % p.tiles_y, cmb = r1 / p.tiles_y;
@@ -419,11 +419,11 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (p.dbg) { t1 = stamp(); tsum[3] += t1 - t0; t0 = t1; }
+        if (kStamps && p.dbg) { t1 = stamp(); tsum[3] += t1 - t0; t0 = t1; }
         __syncthreads();
-        if (p.dbg) { t1 = stamp(); tsum[4] += t1 - t0; tsum[5] += 1; }
+        if (kStamps && p.dbg) { t1 = stamp(); tsum[4] += t1 - t0; tsum[5] += 1; }
     }
-    if (p.dbg && lane == 0) {
+    if (kStamps && p.dbg && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) p.dbg[((size_t)blockIdx.x * 8 + wave) * 6 + i] = tsum[i];
     }
@@ -465,7 +465,7 @@ static int gconv_pick_th(const avl_seg_op& op, int comb, int cus, int* nsp_out, 
     const int ncomb = comb ? op.dil * op.dil : 1, cchunks = op.in_c / CC;
     int best = 0;
     double best_cost = 0.;
-    static const int env_th = getenv("AVL_GCONV_TH") ? atoi(getenv("AVL_GCONV_TH")) : 0;      // experiments
+    const int env_th = AVL_EXP_INT("AVL_GCONV_TH", 0);      // experiments build only
     for (int th = 8; th >= 2; th >>= 1) {
         if (2 * gconv_tile_bytes(op.stride, d, th, mx) > 160 * 1024) continue;
         if (mx && th == 8) continue;                 // the MX variant with four sub-tiles per wave spills
@@ -533,21 +533,30 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
         AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv_mfma<HT, WS, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_gconv_mfma<HT, WS, NJ>), dim3(a.nslots * a.cchunks), dim3(512), 2 * a.tile_bytes, s, a);             \
     } while (0)
-    static const int dephase = getenv("AVL_GC_DEPHASE") ? atoi(getenv("AVL_GC_DEPHASE")) : 1;
-    a.dephase = dephase;
+    a.dephase = AVL_EXP_INT("AVL_GC_DEPHASE", 1);
     a.dbg = nullptr;
-    static const int probe = getenv("AVL_GC_PROBE") ? atoi(getenv("AVL_GC_PROBE")) : 0;       // timing experiment: where do a wave's cycles go
+#ifdef AVL_EXPERIMENTS
+    // timing experiment: where do a wave's cycles go (s_memtime stamps; synchronises the stream: never inside a graph capture)
     static unsigned long long* dbg = nullptr;
-    if (probe) {
+    if (AVL_EXP_INT("AVL_GC_PROBE", 0)) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        AVL_HIP_CHECK(hipStreamIsCapturing(s, &cap));
+        AVL_REQUIRE(cap == hipStreamCaptureStatusNone, "AVL_GC_PROBE synchronises the stream: not while it is being captured (MODEL.HIP_GRAPH = False)");
         if (!dbg) AVL_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&dbg), 256 * 8 * 6 * sizeof(unsigned long long), 0));
         memset(dbg, 0, 256 * 8 * 6 * sizeof(unsigned long long));
         if (a.nslots * a.cchunks <= 256) a.dbg = dbg;
     }
-    if (a.th == 8) AVL_GCONV_LAUNCH(4);
+#endif
+    // (the MX variant never runs four sub-tiles per wave -- gconv_pick_th: it would spill -- so that kernel is not even instantiated)
+    if (a.th == 8) {
+        if constexpr (WS != 2) AVL_GCONV_LAUNCH(4);
+        else return avl::set_error(AVL_E_ARG, "MX grouped conv: tile height 8 is not built");
+    }
     else if (a.th == 4) AVL_GCONV_LAUNCH(2);
     else AVL_GCONV_LAUNCH(1);
 #undef AVL_GCONV_LAUNCH
     AVL_LAUNCH_CHECK();
+#ifdef AVL_EXPERIMENTS
     if (a.dbg) {
         AVL_HIP_CHECK(hipStreamSynchronize(s));
         double sum[6] = {};
@@ -557,6 +566,7 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
         fprintf(stderr, "[gconv probe] C %d dil %d stride %d th %d WS %d tiles/wg %.1f: cycles per tile: stage %.0f | MFMA phase %.0f | landing wait + zeroing %.0f | epilogue %.0f | barrier %.0f\n",
                 a.C, a.dil, a.stride, a.th, WS, n / (a.nslots * a.cchunks * 8), sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n);
     }
+#endif
     return AVL_OK;
 }
 

@@ -516,7 +516,8 @@ int launch_ring(const GemmArgs& a0, int M, hipStream_t s) {
     const int mtiles = (M + BM - 1) / BM;
     const int total = mtiles * a.ntiles;
     const int grid = total < 256 ? total : 256;
-    static const int probe = getenv("AVL_GEMM_PROBE") ? atoi(getenv("AVL_GEMM_PROBE")) : 0;   // timing experiments only
+#ifdef AVL_EXPERIMENTS
+    const int probe = AVL_EXP_INT("AVL_GEMM_PROBE", 0);     // timing experiments only: the results are garbage
     if (probe >= 1 && probe <= 3 && NSUB == 1 && IO == 0) {
 #define AVL_PROBE_LAUNCH(P)                                                                                                                     \
     do {                                                                                                                                        \
@@ -528,6 +529,7 @@ int launch_ring(const GemmArgs& a0, int M, hipStream_t s) {
         else AVL_PROBE_LAUNCH(3);
 #undef AVL_PROBE_LAUNCH
     } else
+#endif
         hipLaunchKernelGGL((k_gemm_ring<H, WM, WN, MI, STAGES, 0, NSUB, IO, AST>), dim3(grid), dim3(WM * WN * 64), LDS, s, a, mtiles);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
@@ -1160,7 +1162,7 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
         };
         auto readAn = [&](int t) {                               // ... of the NEXT sub-step (its slot, its kind)
             Af[t] = rdA(abn, t / MI, t % MI);
-            if (next_q) As[t] = rdAs(sbn, t / MI, t % MI);
+            As[t] = rdAs(sbn, t / MI, t % MI);                   // (unconditional: see Wsn below)
         };
         if (PROBE == 3 && S == 0) { const unsigned long long t = stamp(); if (tlast) tsum[0] += t - tlast; tlast = t; tsum[5] += 1; }
         if (EW != EV && S == EW) {
@@ -1217,7 +1219,10 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
 #pragma unroll
                 for (int nj = 0; nj < 4; ++nj) Wf[0][nj] = rdW(wbn, 0, nj);
             }
-            if (next_q) Wsn = rdWs(sbn);
+            // Scales are read ahead whether or not the next sub-step is an FP4 one (then they are whatever the slot holds and nothing
+            // uses them): a read under the run-time flag would keep Wsn / Wsc / As[0 .. 2] LIVE through every f16 sub-step (seven
+            // registers hipcc spilled to scratch and reloaded inside the hand-counted stream); four LDS reads per sub-step are free.
+            Wsn = rdWs(sbn);
             readAn(0);
         }
         if (PROBE != 1 && !early && (EW == EV || LATE != 0) && S == EV + LATE && pt < total) {
@@ -1300,8 +1305,7 @@ template <int IO, int MI>
 int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
     constexpr int BM = 2 * MI * 16, LDS = 2 * (BM + 256) * 128 + 2 * 4096;
     MxArgs a = a0;
-    static const int stagger = getenv("AVL_MX_STAGGER") ? atoi(getenv("AVL_MX_STAGGER")) : 1;
-    a.stagger = stagger;
+    a.stagger = AVL_EXP_INT("AVL_MX_STAGGER", 1);
     a.g.ntiles = a.g.N / 256;
     const int mtiles = (a.g.M + BM - 1) / BM;
     const int total = mtiles * a.g.ntiles;
@@ -1310,23 +1314,28 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
     // and conv3 + downsample), the round-2 kernel (two plain barriers per sub-step, a cheaper tile switch) where a tile is only 1-2 K
     // macro-blocks (K = 256 / 512: layer2, layer3 conv3, the decoder's pointwise convs: the stream is +2...+19 % there);
     // profiles/r03/gemm_mx_pipe_vs_ring_ab.log.  AVL_MX_PIPE = 0 / 1 forces one of them (A/B experiments).
-    static const int pipe_env = getenv("AVL_MX_PIPE") ? atoi(getenv("AVL_MX_PIPE")) : -1;
+    const int pipe_env = AVL_EXP_INT("AVL_MX_PIPE", -1);
     const bool pipe = pipe_env >= 0 ? pipe_env != 0 : a.g.K >= 1024;
-    static const int late_env = getenv("AVL_MX_LATE") ? atoi(getenv("AVL_MX_LATE")) : -1;
     if (pipe) {
         // LATE: how many steps behind the event(s) waves 0-3 issue their bursts (waves 4-7: right behind them)
-        constexpr int L0 = MI == 8 ? 0 : 1, L1 = 2;
-        static const int probe = getenv("AVL_MX_PROBE") ? atoi(getenv("AVL_MX_PROBE")) : 0;       // timing experiments only (256-row tiles)
+        constexpr int L0 = MI == 8 ? 0 : 1;
 #define AVL_PIPE_LAUNCH(...)                                                                                                                   \
     do {                                                                                                                                       \
         AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_mx_pipe<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
         hipLaunchKernelGGL((k_gemm_mx_pipe<__VA_ARGS__>), dim3(grid), dim3(512), LDS, s, a, mtiles);                                           \
     } while (0)
+#ifdef AVL_EXPERIMENTS
+        constexpr int L1 = 2;
+        const int late_env = AVL_EXP_INT("AVL_MX_LATE", -1);
+        const int probe = AVL_EXP_INT("AVL_MX_PROBE", 0);       // timing experiments only (256-row tiles): 1, 2, 4, 5 give garbage results
         if (MI == 8 && probe == 1) AVL_PIPE_LAUNCH(IO, 8, 0, 1);
         else if (MI == 8 && probe == 2) AVL_PIPE_LAUNCH(IO, 8, 0, 2);
         else if (MI == 8 && probe == 4) AVL_PIPE_LAUNCH(IO, 8, 0, 4);
         else if (MI == 8 && probe == 5) AVL_PIPE_LAUNCH(IO, 8, 0, 5);
         else if (MI == 8 && probe == 3) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            AVL_HIP_CHECK(hipStreamIsCapturing(s, &cap));
+            AVL_REQUIRE(cap == hipStreamCaptureStatusNone, "AVL_MX_PROBE=3 synchronises the stream: not while it is being captured (MODEL.HIP_GRAPH = False)");
             static unsigned long long* dbg = nullptr;
             if (!dbg) AVL_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&dbg), 256 * 8 * 8 * sizeof(unsigned long long), 0));
             memset(dbg, 0, 256 * 8 * 8 * sizeof(unsigned long long));
@@ -1344,7 +1353,9 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
             }
         }
         else if (late_env == L1) AVL_PIPE_LAUNCH(IO, MI, L1);
-        else AVL_PIPE_LAUNCH(IO, MI, L0);
+        else
+#endif
+            AVL_PIPE_LAUNCH(IO, MI, L0);
 #undef AVL_PIPE_LAUNCH
     } else {
         AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring_mx<IO, MI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -1356,7 +1367,7 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
 
 int launch_ring_mx(const MxArgs& a, bool quantize_out, hipStream_t s) {
     // 128-row tiles when 256-row tiles would leave more than a quarter of the 256 CUs idle (or give a ragged second wave)
-    static const int force = getenv("AVL_MX_TILE") ? atoi(getenv("AVL_MX_TILE")) : 0;       // 128 / 256: experiments
+    const int force = AVL_EXP_INT("AVL_MX_TILE", 0);       // 128 / 256: experiments
     const long long t256 = (long long)((a.g.M + 255) / 256) * (a.g.N / 256);
     const bool small = force ? force == 128 : (t256 < 192 || (t256 > 256 && t256 < 384));
     if (small) return quantize_out ? launch_ring_mx_t<1, 4>(a, s) : launch_ring_mx_t<0, 4>(a, s);
@@ -1429,10 +1440,16 @@ int validate_gemm(const avl_seg_op& op) {
     return AVL_OK;
 }
 
+#ifdef AVL_EXPERIMENTS
 int launch_gemm_w4(const avl_seg_op& op, hipStream_t s);      // seg_gemm_w4.hip: one-wave-per-SIMD experiment (w_layout = 5)
+#endif
 
 int launch_gemm(const avl_seg_op& op, hipStream_t s) {
+#ifdef AVL_EXPERIMENTS
     if (op.w_layout == 5) return launch_gemm_w4(op, s);
+#else
+    AVL_REQUIRE(op.w_layout != 5, "GEMM w_layout 5 (k_gemm_w4) exists in the experiments build only (make experiments)");
+#endif
     GemmArgs a;
     a.A = op.in; a.W = op.weight; a.bias = op.bias; a.R = op.in2; a.C = op.out;
     a.lda = op.in_ld; a.ldr = op.in2_ld; a.ldc = op.out_ld;
@@ -1503,7 +1520,7 @@ int launch_gemm(const avl_seg_op& op, hipStream_t s) {
         int v = op.w_layout;
         if (v == 0) v = (can256 && ((a.M + 255) / 256) * (a.N / 256) >= 192) ? 3 : 2;
         if (a.nsub == 2) {
-            static const int deep = getenv("AVL_GEMM_DEEP") ? atoi(getenv("AVL_GEMM_DEEP")) : 1;      // A/B: 0 = 2 + 2 tiles, one sub-step ahead
+            const int deep = AVL_EXP_INT("AVL_GEMM_DEEP", 1);      // A/B: 0 = 2 + 2 tiles, one sub-step ahead
             if (v == 3 && can256) return deep ? launch_ring<f16, 2, 4, 8, 3, 2, 1, 2>(a, a.M, s) : launch_ring<f16, 2, 4, 8, 2, 2, 1>(a, a.M, s);
             return launch_ring<f16, 4, 2, 4, 3, 2, 1>(a, a.M, s);
         }

@@ -287,27 +287,39 @@ class SemanticMapping(object):
         n = int(msg.width) * int(msg.height)
         step = int(msg.point_step)
         nbytes = n * step
-        points = torch.empty((max(n, 1), 4), dtype=torch.float32, device=self.device)[:n]
-        count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # Everything this call enqueues -- the zero-fill of `count`, the upload, the kernel -- goes on ONE stream `st` (the caller's,
+        # or torch's current one), and the tensors it returns are allocated under that stream so that the caching allocator
+        # knows who uses them (with an explicit stream the zero-fill used to run on torch's current stream and could
+        # race with the kernel's atomic increments).
+        st = torch.cuda.current_stream(self.device) if stream is None else torch.cuda.ExternalStream(int(stream), device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        if st.cuda_stream != cur.cuda_stream:
+            st.wait_stream(cur)                                # earlier work of the caller on the current stream (e.g. a frame still reading `dev`)
+        with torch.cuda.stream(st):
+            points = torch.empty((max(n, 1), 4), dtype=torch.float32, device=self.device)[:n]
+            count = torch.zeros(1, dtype=torch.int32, device=self.device)
         if n == 0:
             return points, count
         payload = _pointcloud2_payload(msg)                   # uint8 [n * point_step]: rows without their row_step padding
         if self._pc2_stage is None or self._pc2_stage[0].numel() < nbytes:
             cap = max(nbytes, 1 << 22)
             self._pc2_stage = (torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device),
-                               torch.cuda.Event())
-        host, dev, staged = self._pc2_stage
-        # copy and kernel are enqueued on ONE stream (the caller's, or torch's current one), so the kernel reads what the copy
-        # wrote; the pinned buffer is reused only after the previous message's copy has executed (the event), and the device
-        # staging buffer is only ever touched on that stream order
-        st = torch.cuda.current_stream(self.device) if stream is None else torch.cuda.ExternalStream(int(stream), device=self.device)
+                               torch.cuda.Event(), torch.cuda.Event())
+        host, dev, staged, unpacked = self._pc2_stage
+        # The kernel reads what the copy wrote (same stream).  The pinned buffer is reused only after the previous message's copy
+        # has executed (`staged`), the shared device staging buffer only after the previous message's KERNEL has (`unpacked`:
+        # this stream waits for it, so consecutive calls may use different streams).
         staged.synchronize()                                   # no-op for a never-recorded event
         host.numpy()[:nbytes] = payload                        # one memcpy into pinned memory
         with torch.cuda.stream(st):
+            st.wait_event(unpacked)
             dev[:nbytes].copy_(host[:nbytes], non_blocking=True)
             staged.record(st)
         rc = _lib.lib().avl_unpack_pointcloud2(_ptr(dev), n, step, offs["x"], offs["y"], offs["z"], offs["intensity"], _ptr(points),
                                                _ptr(count), C.c_void_p(st.cuda_stream))
+        unpacked.record(st)
+        if st.cuda_stream != cur.cuda_stream:
+            dev.record_stream(st)                              # (the staging buffer lives in the current stream's allocator pool)
         _lib.check(rc, "avl_unpack_pointcloud2")
         return points, count
 
