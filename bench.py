@@ -175,13 +175,15 @@ def main():
         if not args.no_cpu_baseline:
             parity, cpu_baseline, logits_ref = parity_and_cpu_baseline(net, state, cfg, sm.confusion_matrix, cam, image, image_host, points,
                                                                        dev, want_baseline=(world == 1))
-            # a second weights draw (the logits error follows the weights): same frame, same cloud
+            # a second weights draw (the logits error follows the weights): same frame, same cloud.  That draw's
+            # arg-max map is almost never one of the reference's five map classes (3 cells touched: a vacuous grid check), so ITS five
+            # most frequent classes play the five map classes, on both sides
             parity = {"weight_seed_0": parity}
             for seed2 in PARITY_EXTRA_SEEDS:
                 st2 = random_state_dict(seed2)
                 net2 = SegNet(st2, H, W, precision=args.precision, device=dev, **mixed_opts)
                 parity["weight_seed_%d" % seed2] = parity_and_cpu_baseline(net2, st2, cfg, sm.confusion_matrix, cam, image, image_host, points,
-                                                                           dev, want_baseline=False)[0]
+                                                                           dev, want_baseline=False, remap_votes=True)[0]
                 del net2
                 torch.cuda.empty_cache()
             parity["worst"] = worst_parity([v for k, v in parity.items() if k.startswith("weight_seed_")])
@@ -198,6 +200,9 @@ def main():
             "grid_e2e_cells_differing_frac": None if parity is None else parity["worst"]["grid_e2e_cells_differing_frac"],
             "grid_same_labels_max_abs_dlogodds": None if parity is None else parity["worst"]["grid_same_labels_max_abs_dlogodds"],
             "logits_max_rel_err_vs_oracle": None if parity is None else parity["worst"]["logits_max_rel_err"],
+            # every label pixel whose arg-max differs from the oracle's is a near-tie of the ORACLE's logits: its winner beats the class
+            # the GPU picked by at most this much (relative to max|logit|; bounded by 2 x the logits tolerance)
+            "flip_margin_max_rel": None if parity is None else parity["worst"]["flip_margin_max_rel"],
             "exchange_ms": None if exchange_ms is None else round(exchange_ms, 3), "exchange_bytes": exchange_bytes,
             "config": {"workload": "configs[2] full fuse: seg 1920x1080 + projection + 0.2 m BEV log-odds update, 120k pts, "
                                    "2000x2000x5 f64 grid; weights random-init ResNeXt50-OS8 DeepLabV3+",
@@ -220,9 +225,10 @@ def worst_parity(blocks):
     """field-by-field worst of several parity blocks (max of the errors and counts, min of the agreement)"""
     out = {}
     for key in ("logits_max_rel_err", "label_pixels_differing", "grid_same_labels_max_abs_dlogodds", "grid_e2e_max_abs_dlogodds",
-                "grid_e2e_cells_differing", "grid_e2e_cells_differing_frac"):
+                "grid_e2e_cells_differing", "grid_e2e_cells_differing_frac", "flip_margin_max_rel", "flip_top2_margin_max_rel"):
         out[key] = max(b[key] for b in blocks)
     out["argmax_agreement"] = min(b["argmax_agreement"] for b in blocks)
+    out["grid_cells_touched"] = min(b["grid_cells_touched"] for b in blocks)
     return out
 
 
@@ -408,10 +414,38 @@ def other_precisions(default_precision, state, cfg, cm, cam, image, points, dev,
     return out
 
 
-def parity_and_cpu_baseline(net, state, cfg, cm, cam, image, image_host, points, dev, want_baseline):
+def flip_margins(logits_ref, labels_ref, labels_gpu):
+    """Where the GPU's arg-max differs from the oracle's: by how much does the ORACLE's winner beat (a) the class the GPU picked,
+    (b) its own runner-up, relative to max|logit| (vision_semantic_segmentation_node.py:101-102 commits to a label there).  With
+    logits within eps of the oracle's, (b) <= (a) <= 2 eps: a flip can only be a near-tie.  Returns (a, b) maxima; (0, 0) without flips."""
+    lr = logits_ref.numpy() if hasattr(logits_ref, "numpy") else np.asarray(logits_ref)
+    flip = labels_ref != labels_gpu
+    if not flip.any():
+        return 0.0, 0.0
+    scale = float(np.abs(lr).max())
+    cols = lr[:, flip]                                        # [19, flips]
+    top = np.sort(cols, axis=0)
+    picked = cols[labels_gpu[flip].astype(np.int64), np.arange(cols.shape[1])]
+    return float((top[-1] - picked).max() / scale), float((top[-1] - top[-2]).max() / scale)
+
+
+def host_threads():
+    """(os.cpu_count(), BLAS threads of NumPy's backend) for the cpu_baseline block"""
+    blas = None
+    try:
+        from threadpoolctl import threadpool_info
+        blas = max([int(i.get("num_threads", 0)) for i in threadpool_info() if i.get("user_api") == "blas"] or [0]) or None
+    except Exception:
+        pass
+    return os.cpu_count(), blas
+
+
+def parity_and_cpu_baseline(net, state, cfg, cm, cam, image, image_host, points, dev, want_baseline, remap_votes=False):
     """Parity of this very workload.  The oracle network (torch CPU fp32) runs ONCE on the full 1080 x 1920 frame: its
     logits check the GPU's, its own arg-max feeds the oracle mapping, and its wall time is the network half of the CPU
-    baseline."""
+    baseline.  remap_votes: the five most frequent classes of the oracle's label map take the roles of the reference's five map
+    classes (LABEL_COLORS = their palette colours, on both sides), so that a weights draw whose arg-max never hits
+    LABELS = [2, 1, 8, 10, 3] still votes into > 10 000 cells."""
     import torch
     from oracle import mapping_oracle as mo
     from oracle import network_oracle as no
@@ -419,47 +453,67 @@ def parity_and_cpu_baseline(net, state, cfg, cm, cam, image, image_host, points,
     from vision_semantic_segmentation_amd.utils.logger import MyLogger
     labels_gpu = net.forward(image).clone()
     logits_gpu = net.logits.permute(2, 0, 1).float().cpu()
-    sm2 = SemanticMapping(cfg, device=dev, logger=MyLogger("bench", quiet=True))
-    sm2.confusion_matrix = cm
-    sm2.frame_device(points, "velodyne", labels_gpu, None, cam, src_kind="classmap", image_size=(H, W))
-    grid_gpu = sm2.map
     no.forward_logits(state, image_host[:96, :128])          # warm-up (thread pool, allocator)
     t0 = time.perf_counter()
     logits_ref = no.forward_logits(state, image_host)[0]
     t_net = time.perf_counter() - t0
     labels_ref = logits_ref.argmax(0).numpy().astype(np.uint8)
+    label_colors, vote_classes = mo.LABEL_COLORS, list(mo.LABELS)
+    if remap_votes:
+        counts = np.bincount(labels_ref.ravel(), minlength=19)
+        vote_classes = [int(c) for c in np.argsort(-counts, kind="stable")[:5]]
+        label_colors = [list(mo.PALETTE_19[c]) for c in vote_classes]
+    sm2 = SemanticMapping(cfg, device=dev, logger=MyLogger("bench", quiet=True))
+    sm2.confusion_matrix = cm
+    sm2.label_colors = np.array(label_colors)
+    sm2.frame_device(points, "velodyne", labels_gpu, None, cam, src_kind="classmap", image_size=(H, W))
+    grid_gpu = sm2.map
     rel = float((logits_gpu - logits_ref).abs().max() / logits_ref.abs().max())
-    agree = float((torch.from_numpy(labels_ref) == labels_gpu.cpu()).float().mean())
+    labels_gpu_h = labels_gpu.cpu().numpy()
+    agree = float((labels_ref == labels_gpu_h).mean())
+    margin_picked, margin_top2 = flip_margins(logits_ref, labels_ref, labels_gpu_h)
     ocfg = dict(range_max=100.0, boundary=cfg.MAPPING.BOUNDARY, resolution=GRID_RES, label_names=mo.LABELS_NAMES,
-                label_colors=mo.LABEL_COLORS, confusion_matrix=cm, use_pcd_intensity=True)
+                label_colors=label_colors, confusion_matrix=cm, use_pcd_intensity=True)
     pcd64 = points.cpu().numpy().T.astype(np.float64)
 
     def oracle_grid(lab):
         sem = mo.semantic_image_from_labels(lab, H, W)
         grid = np.zeros(grid_gpu.shape)
-        t = time.perf_counter()
         mo.mapping_frame(grid, pcd64, "velodyne", sem, None, cam.P, ocfg)
-        return grid, time.perf_counter() - t
+        return grid, sem
 
-    grid_own, t_map = oracle_grid(labels_ref)                  # oracle network -> oracle mapping (end to end)
-    grid_same, t_map2 = oracle_grid(labels_gpu.cpu().numpy())   # oracle mapping fed the GPU's label map (mapping only)
+    grid_own, sem_own = oracle_grid(labels_ref)                # oracle network -> oracle mapping (end to end)
+    grid_same, _ = oracle_grid(labels_gpu_h)                   # oracle mapping fed the GPU's label map (mapping only)
     d_e2e = np.abs(grid_gpu - grid_own)
     parity = {
         "precision": net.precision, "logits_max_rel_err": rel, "argmax_agreement": agree,
-        "label_pixels_differing": int((torch.from_numpy(labels_ref) != labels_gpu.cpu()).sum()),
+        "label_pixels_differing": int((labels_ref != labels_gpu_h).sum()),
+        "flip_margin_max_rel": margin_picked, "flip_top2_margin_max_rel": margin_top2,
         "grid_same_labels_max_abs_dlogodds": float(np.max(np.abs(grid_gpu - grid_same))),
         "grid_e2e_max_abs_dlogodds": float(d_e2e.max()), "grid_e2e_cells_differing": int((d_e2e.max(axis=2) > 0).sum()),
-        "grid_cells_touched": int((grid_own != 0).any(axis=2).sum()),
+        "grid_cells_touched": int((grid_own != 0).any(axis=2).sum()), "vote_classes": vote_classes,
         "grid_e2e_cells_differing_frac": float((d_e2e.max(axis=2) > 0).sum()) / max(1, int((grid_own != 0).any(axis=2).sum())),
         "note": "e2e = HIP network -> HIP mapping against oracle network -> oracle mapping; a grid cell differs only where a LiDAR "
-                "point lands on one of the label pixels whose arg-max flipped (near-ties within the logits tolerance)",
+                "point lands on one of the label pixels whose arg-max flipped; every such pixel is a near-tie of the oracle's own "
+                "logits (flip_margin_max_rel <= 2 x the logits tolerance)",
     }
     baseline = None
     if want_baseline:
-        t_map = min(t_map, t_map2)
+        # NumPy restatement of a7 + a8 on the same inputs, 1 process, min of >= 5 repetitions after 3 warm-ups
+        times = []
+        for rep in range(8):
+            grid = np.zeros(grid_gpu.shape)
+            t = time.perf_counter()
+            mo.mapping_frame(grid, pcd64, "velodyne", sem_own, None, cam.P, ocfg)
+            if rep >= 3:
+                times.append(time.perf_counter() - t)
+        t_map = min(times)
+        ncpu, blas = host_threads()
         baseline = {"value": round(1.0 / (t_net + t_map), 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                    "sample": "one full 1080x1920 frame + 120k points: oracle network (torch CPU fp32, %d threads) %.2f s, oracle mapping "
-                              "(NumPy, 1 thread, min of 2) %.1f ms" % (torch.get_num_threads(), t_net, 1e3 * t_map)}
+                    "host_cpu_count": ncpu, "blas_threads": blas, "network_s": round(t_net, 3), "mapping_ms": round(1e3 * t_map, 2),
+                    "sample": "one full 1080x1920 frame + 120k points: oracle network (torch CPU fp32, %d threads, once after a small warm-up "
+                              "frame) %.2f s, oracle mapping (NumPy, 1 process, BLAS threads %s, min of %d after 3 warm-ups) %.1f ms; "
+                              "os.cpu_count() = %s" % (torch.get_num_threads(), t_net, blas, len(times), 1e3 * t_map, ncpu)}
     return parity, baseline, logits_ref
 
 

@@ -69,14 +69,20 @@ def test_hip_net_and_grid_against_oracle_net_and_grid(hw, cuda_device):
         assert differing <= 4 * flips.sum() * max(1, (H // (H // 4 - 4)) ** 2)
 
 
-def test_configs2_full_size_fused_frame_against_the_oracle(cuda_device):
+@pytest.mark.parametrize("weight_seed", [0, 2])
+def test_configs2_full_size_fused_frame_against_the_oracle(weight_seed, cuda_device):
     """BASELINE configs[2] as ONE fused frame at full size -- the 1080 x 1920 frame and the 120 k-point cloud bench.py times, a
     2000 x 2000 x 5 float64 grid at 0.2 m -- HIP network -> HIP mapping against oracle network -> oracle mapping
     (vision_semantic_segmentation_node.py:101-116 -> mapping.py:314-319).  Asserted: logits within 1e-3; the grid IDENTICAL to
-    the oracle's given the same label map; end to end, cells may differ only through label pixels whose arg-max flipped
-    (near-ties inside the logits tolerance): at most 0.5 % of the touched cells."""
+    the oracle's given the same label map; end to end, cells may differ only through label pixels whose arg-max flipped, at most
+    0.5 % of the touched cells -- and every flipped pixel is a NEAR-TIE of the oracle's own logits: its winner beats the class the
+    GPU picked by <= 2 x 1e-3 x max|logit| (so a flip is never more than the logits tolerance allows).
+    Weight seed 2 (the worst draw of tools/seed_sweep.py) almost never predicts one of the reference's five map classes
+    (mapping.py:414-424 only votes for LABELS = [2, 1, 8, 10, 3]): there the five most frequent classes of the oracle's label map
+    play the five map classes on both sides, so that the grid check is not vacuous (> 10 000 cells)."""
     import torch
     import _full_size as fs
+    from bench import flip_margins
     from oracle import mapping_oracle as mo
     from vision_semantic_segmentation_amd import SemanticMapping, SemanticSegmentation, get_cfg_defaults
     from vision_semantic_segmentation_amd import synthetic as syn
@@ -86,22 +92,28 @@ def test_configs2_full_size_fused_frame_against_the_oracle(cuda_device):
     cfg = get_cfg_defaults()
     cfg.MAPPING.BOUNDARY = syn.centred_boundary(mo.PCD_ORIGIN_OFFSET[:2], 200.0)
     cfg.MAPPING.RESOLUTION = 0.2
-    seg = SemanticSegmentation(cfg.VISION_SEM_SEG.SEM_SEG_NETWORK, device=cuda_device, state_dict=fs.state_dict(0))
+    seg = SemanticSegmentation(cfg.VISION_SEM_SEG.SEM_SEG_NETWORK, device=cuda_device, state_dict=fs.state_dict(weight_seed))
     assert seg.precision == "mixed"
+    logits_ref = fs.oracle_logits(weight_seed, "bench", H, W)
+    labels_ref = logits_ref.argmax(0).numpy().astype(np.uint8)
+    label_colors = mo.LABEL_COLORS
+    if weight_seed != 0:
+        counts = np.bincount(labels_ref.ravel(), minlength=19)
+        label_colors = [list(mo.PALETTE_19[int(c)]) for c in np.argsort(-counts, kind="stable")[:5]]
     sm = SemanticMapping(cfg, device=cuda_device, logger=MyLogger("t", quiet=True))
     sm.confusion_matrix = syn.log_confusion(5)
+    sm.label_colors = np.array(label_colors)
     assert (sm.map_height, sm.map_width, sm.map_depth) == (2000, 2000, 5)
     points = torch.from_numpy(np.ascontiguousarray(pcd.T.astype(np.float32))).to(cuda_device)       # PointCloud2 layout, as in bench.py
     labels_dev = seg.segmentation_device(img).clone()
     logits = seg.logits(img).float().cpu()
     sm.frame_device(points, "velodyne", labels_dev, None, cam, src_kind="classmap", image_size=(H, W))
     got = sm.map
-    logits_ref = fs.oracle_logits(0, "bench", H, W)
     rel = float((logits - logits_ref).abs().max() / logits_ref.abs().max())
-    labels_ref = logits_ref.argmax(0).numpy().astype(np.uint8)
     flips = int((labels_ref != labels_dev.cpu().numpy()).sum())
+    margin_picked, margin_top2 = flip_margins(logits_ref, labels_ref, labels_dev.cpu().numpy())
     ocfg = dict(range_max=100.0, boundary=cfg.MAPPING.BOUNDARY, resolution=0.2, label_names=mo.LABELS_NAMES,
-                label_colors=mo.LABEL_COLORS, confusion_matrix=sm.confusion_matrix, use_pcd_intensity=True)
+                label_colors=label_colors, confusion_matrix=sm.confusion_matrix, use_pcd_intensity=True)
     pcd64 = points.cpu().numpy().T.astype(np.float64)
 
     def oracle_grid(lab):
@@ -113,10 +125,12 @@ def test_configs2_full_size_fused_frame_against_the_oracle(cuda_device):
     grid_own = oracle_grid(labels_ref)
     touched = int((grid_own != 0).any(axis=2).sum())
     differing = int((np.abs(got - grid_own).max(axis=2) > 0).sum())
-    print("configs[2] fused frame: logits rel err %.3e, %d label pixels flipped, %d of %d touched cells differ end to end (max %.3f)"
-          % (rel, flips, differing, touched, float(np.abs(got - grid_own).max())))
+    print("configs[2] fused frame, weights seed %d: logits rel err %.3e, %d label pixels flipped (oracle margin to the picked class <= %.3e, "
+          "top-2 margin <= %.3e of max|logit|), %d of %d touched cells differ end to end (max %.3f)"
+          % (weight_seed, rel, flips, margin_picked, margin_top2, differing, touched, float(np.abs(got - grid_own).max())))
     assert rel <= 1e-3
     assert touched > 10000
+    assert margin_top2 <= margin_picked <= 2 * 1e-3              # flips are near-ties only
     assert np.array_equal(got, grid_same)                        # float64 grid, same labels: bit for bit
     assert differing <= 0.005 * touched
     assert differing <= 16 * flips                               # one source pixel covers 4 x 4 image pixels: few points, few cells
