@@ -976,6 +976,7 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
     constexpr int A_INSTR = BM / 8 / NW, W_INSTR = BN / 8 / NW;
     constexpr int NS = 2 * MI, D = 3, EV = NS - D;              // steps per sub-step; fragments are read D steps ahead; the (main) event sits in front of step EV
     constexpr int EW = MI == 8 ? 5 : EV;                         // ... and the weight-slot event (MI = 4: one event for both slots)
+    constexpr bool SPR = SPREAD == 1 || SPREAD == 2, PIN = SPREAD != 0;     // experiments: DMA schedules 1 / 2; 3 = the release schedule with pinned MFMAs
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const GemmArgs& p = q.g;
 
@@ -1179,7 +1180,7 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
         if (EW != EV && S == EW) {
             // complementary bursts: waves 0-3 send the ACTIVATION tile of the sub-step after next here, one event after waves 4-7
             // did (its slot was released at the previous main event; not in the very first sub-step: that tile is already in flight)
-            if (SPREAD == 0 && LATE == 0 && !early && g > 0 && PROBE != 1 && pt < total) {
+            if (!SPR && LATE == 0 && !early && g > 0 && PROBE != 1 && pt < total) {
                 unsigned long long t1 = 0;
                 if (PROBE == 3) t1 = stamp();
                 issue_a();
@@ -1194,10 +1195,10 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             __builtin_amdgcn_sched_barrier(0);
             unsigned long long t1 = 0;
             if (PROBE == 3) { t1 = stamp(); tsum[1] += t1 - t0; }
-            if (SPREAD == 0 && PROBE != 1 && early && pt < total) { issue_w(); w_sent = true; }
+            if (!SPR && PROBE != 1 && early && pt < total) { issue_w(); w_sent = true; }
             if (PROBE == 3) tsum[2] += stamp() - t1;
         }
-        if (SPREAD == 0 && EW != EV && LATE != 0 && !early && S == EW + LATE && PROBE != 1 && pt < total) {
+        if (!SPR && EW != EV && LATE != 0 && !early && S == EW + LATE && PROBE != 1 && pt < total) {
             unsigned long long t1 = 0;
             if (PROBE == 3) t1 = stamp();
             issue_w();
@@ -1208,7 +1209,7 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             // every read of this slot was issued >= 2 steps ago.  DMA: the only operations this wave may still have in flight
             // are the W_INSTR of the weight burst it issued a few steps ago (for the sub-step after next); everything older
             // -- both tiles of the next sub-step, epilogue stores -- is waited for
-            if (SPREAD == 0 && EW != EV && LATE == 0 && !early && PROBE != 1 && pt < total) {
+            if (!SPR && EW != EV && LATE == 0 && !early && PROBE != 1 && pt < total) {
                 unsigned long long t1 = 0;
                 if (PROBE == 3) t1 = stamp();
                 issue_w();
@@ -1224,7 +1225,7 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             __builtin_amdgcn_sched_barrier(0);
             unsigned long long t1 = 0;
             if (PROBE == 3) { t1 = stamp(); tsum[3] += t1 - t0; }
-            if (SPREAD == 0 && PROBE != 1 && early && pt < total) { if (EW == EV) issue_w(); issue_a(); }
+            if (!SPR && PROBE != 1 && early && pt < total) { if (EW == EV) issue_w(); issue_a(); }
             if (PROBE == 3) tsum[4] += stamp() - t1;
             if (PROBE != 4 || g < 2) {
 #pragma unroll
@@ -1236,14 +1237,14 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             Wsn = rdWs(sbn);
             readAn(0);
         }
-        if (SPREAD == 0 && PROBE != 1 && !early && (EW == EV || LATE != 0) && S == EV + LATE && pt < total) {
+        if (!SPR && PROBE != 1 && !early && (EW == EV || LATE != 0) && S == EV + LATE && pt < total) {
             unsigned long long t1 = 0;
             if (PROBE == 3) t1 = stamp();
             if (EW == EV) issue_w();
             issue_a();
             if (PROBE == 3) tsum[4] += stamp() - t1;
         }
-        if constexpr (SPREAD != 0) {
+        if constexpr (SPR) {
             // SPREAD: no bursts.  Every step, one wave of each SIMD sends ONE DMA instruction: waves 4-7 on the odd steps, waves 0-3
             // on the even ones -- the weight tile of sub-step g + 2 in steps 5 .. 12 (behind EW, which releases its slot), its
             // activation tile in steps 13 .. 15 (behind EV) and 0 .. 4 of the next sub-step.  Four 1 KB instructions per step and CU
@@ -1252,14 +1253,25 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             // four youngest operations of a wave are exactly its weight pieces of steps 5 .. 12, everything older (the activation
             // pieces of the tile that is certified there included, the last of them issued at step 3 / 4) is waited for.
             static_assert(MI == 8 && EW == 5 && EV == 13, "SPREAD: 16-step sub-steps only");
-            if constexpr (S >= 5 && S <= 12) {
-                if (early == ((S & 1) == 1) && pt < total) { issue_w((S - 5) / 2); w_sent = true; }
+            if constexpr (SPREAD == 1) {
+                if constexpr (S >= 5 && S <= 12) {
+                    if (early == ((S & 1) == 1) && pt < total) { issue_w((S - 5) / 2); w_sent = true; }
+                }
+                constexpr int pa_e = S == 13 ? 0 : S == 15 ? 1 : S == 1 ? 2 : S == 3 ? 3 : -1;
+                constexpr int pa_l = S == 14 ? 0 : S == 0 ? 1 : S == 2 ? 2 : S == 4 ? 3 : -1;
+                // (g == 0: the prologue has sent sub-steps 0 and 1 whole)
+                if constexpr (pa_e >= 0) { if (early && pt < total && (S >= 13 || g > 0)) issue_a(pa_e); }
+                if constexpr (pa_l >= 0) { if (!early && pt < total && (S >= 13 || g > 0)) issue_a(pa_l); }
+            } else {
+                // SPREAD = 2: half bursts (two instructions) at four points of the sub-step; waves 4-7 at steps 5 / 9 (weights) and
+                // 13 / 1 (activations), waves 0-3 two steps later
+                constexpr int pw_e = S == 5 ? 0 : S == 9 ? 2 : -1, pw_l = S == 7 ? 0 : S == 11 ? 2 : -1;
+                constexpr int pa_e = S == 13 ? 0 : S == 1 ? 2 : -1, pa_l = S == 15 ? 0 : S == 3 ? 2 : -1;
+                if constexpr (pw_e >= 0) { if (early && pt < total) { issue_w(pw_e); issue_w(pw_e + 1); w_sent = true; } }
+                if constexpr (pw_l >= 0) { if (!early && pt < total) { issue_w(pw_l); issue_w(pw_l + 1); w_sent = true; } }
+                if constexpr (pa_e >= 0) { if (early && pt < total && (S >= 13 || g > 0)) { issue_a(pa_e); issue_a(pa_e + 1); } }
+                if constexpr (pa_l >= 0) { if (!early && pt < total && (S >= 13 || g > 0)) { issue_a(pa_l); issue_a(pa_l + 1); } }
             }
-            constexpr int pa_e = S == 13 ? 0 : S == 15 ? 1 : S == 1 ? 2 : S == 3 ? 3 : -1;
-            constexpr int pa_l = S == 14 ? 0 : S == 0 ? 1 : S == 2 ? 2 : S == 4 ? 3 : -1;
-            // (g == 0: the prologue has sent sub-steps 0 and 1 whole)
-            if constexpr (pa_e >= 0) { if (early && pt < total && (S >= 13 || g > 0)) issue_a(pa_e); }
-            if constexpr (pa_l >= 0) { if (!early && pt < total && (S >= 13 || g > 0)) issue_a(pa_l); }
         }
         // activation fragments: D steps ahead, one per step -- the last one of the slot at step EV - 1, the first of the next slot
         // right behind the event
@@ -1288,7 +1300,7 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             AVL_QMFMA(0); AVL_QMFMA(1); AVL_QMFMA(2); AVL_QMFMA(3);
 #undef AVL_QMFMA
         }
-        if constexpr (SPREAD != 0) {
+        if constexpr (PIN) {
             // with a (uniform) branch in every step hipcc sinks the MFMAs of all sixteen steps below the last branch of the
             // sub-step (one block of 64 MFMAs, every fragment live: 45 spilled registers): an empty volatile asm that "touches" the
             // step's accumulators keeps them in their step
@@ -1715,6 +1727,8 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
         }
         else if (late_env == L1) AVL_PIPE_LAUNCH(IO, MI, L1);
         else if (MI == 8 && AVL_EXP_INT("AVL_MX_SPREAD", 0) == 1) AVL_PIPE_LAUNCH(IO, 8, 0, 0, 1);
+        else if (MI == 8 && AVL_EXP_INT("AVL_MX_SPREAD", 0) == 2) AVL_PIPE_LAUNCH(IO, 8, 0, 0, 2);
+        else if (MI == 8 && AVL_EXP_INT("AVL_MX_SPREAD", 0) == 3) AVL_PIPE_LAUNCH(IO, 8, 0, 0, 3);
         else
 #endif
             AVL_PIPE_LAUNCH(IO, MI, L0);
