@@ -152,6 +152,69 @@ def test_projection_indices_bit_exact_float32_aos(cuda_device):
     assert np.array_equal(mask.cpu().numpy().astype(bool), m)
 
 
+def test_truncating_divisions_on_integer_boundaries(cuda_device):
+    """The kernels replace the IEEE division of `(P X)[0:2] / (P X)[2]` and `(p - b) / res` (mapping.py:375, :408-409) by a
+    reciprocal-multiply + residual correction and fall back to the exact division for lanes whose quotient is within 2^-44 of an
+    integer (csrc/mapping.hip, div_i32_numpy).  Adversarial inputs: quotients that are EXACTLY integers, one ulp either side of one,
+    zero, tiny, huge, negative, zero / tiny / infinite denominators -- int32 pixel indices and grid cells must equal NumPy's."""
+    import ctypes as C
+    import torch
+    from oracle import mapping_oracle as mo
+    from vision_semantic_segmentation_amd import _lib
+    rng = np.random.default_rng(11)
+    # --- pixels: P = [I | 0] so that (P X)[0:2] / (P X)[2] = (x / z, y / z)
+    P = np.zeros((3, 4)); P[0, 0] = P[1, 1] = P[2, 2] = 1.0
+    zs = np.concatenate([rng.uniform(0.1, 50.0, 4000), [1.0, 0.5, 3.0, 0.1, 1e-320, 1e-300, 1e300, 0.0, np.inf, 7.0, 1e-3, 2.0 ** -20]])
+    ks = rng.integers(0, 1900, size=zs.size).astype(np.float64)
+    xs = ks * zs                                                   # x / z is k up to one rounding: exactly k for many z
+    pts = []
+    for dx in (0, 1, -1, 3):                                       # ... and a few ulps either side
+        x = xs.copy()
+        for _ in range(abs(dx)):
+            x = np.nextafter(x, np.inf if dx > 0 else -np.inf)
+        pts.append(np.stack([x, 0.25 * x, zs, np.ones_like(zs)]))
+    pts.append(np.stack([rng.uniform(-50, 50, 20000), rng.uniform(-50, 50, 20000), rng.uniform(-5, 50, 20000), np.ones(20000)]))
+    pcd = np.ascontiguousarray(np.concatenate(pts, axis=1))        # float64 [4, N]
+    n = pcd.shape[1]
+    dev = torch.from_numpy(pcd).to(cuda_device)
+    ixy = torch.empty((2, n), dtype=torch.int32, device=cuda_device)
+    mask = torch.empty(n, dtype=torch.uint8, device=cuda_device)
+    Pc = (C.c_double * 12)(*P.ravel().tolist())
+    W, H = 1920, 1440
+    rc = _lib.lib().avl_project_points(C.c_void_p(dev.data_ptr()), n, _lib.AVL_F64, 8, 8 * n, Pc, None, 1e9, W, H,
+                                       C.c_void_p(ixy.data_ptr()), C.c_void_p(mask.data_ptr()), None)
+    _lib.check(rc)
+    torch.cuda.synchronize()
+    with np.errstate(all="ignore"):
+        _, _, IXY, m = mo.project_pcd(pcd, "velodyne", np.zeros((H, W, 3), dtype=np.uint8), None, P, 1e9, return_debug=True)
+    assert np.array_equal(ixy.cpu().numpy(), IXY)
+    assert np.array_equal(mask.cpu().numpy().astype(bool), m)
+    # --- grid cells: points ON cell boundaries (b + k res, and one ulp either side), resolutions that are and are not binary fractions
+    for res in (0.2, 0.05, 0.25, 0.3):
+        half = 400 * res
+        boundary = [[mo.PCD_ORIGIN_OFFSET[0] - half, mo.PCD_ORIGIN_OFFSET[0] + half], [mo.PCD_ORIGIN_OFFSET[1] - half, mo.PCD_ORIGIN_OFFSET[1] + half]]
+        sm = make_sm(boundary, res, np.eye(5), False, cuda_device)
+        k = rng.integers(-3, sm.map_height + 3, size=6000).astype(np.float64)
+        l = rng.integers(-3, sm.map_width + 3, size=6000).astype(np.float64)
+        xw = (boundary[0][0] + k * res) - mo.PCD_ORIGIN_OFFSET[0]       # update_map adds the offset back: (x + off - b00) / res ~ k
+        yw = (boundary[1][0] + l * res) - mo.PCD_ORIGIN_OFFSET[1]
+        cols = []
+        for d in (0, 1, -1):
+            x, y = xw.copy(), yw.copy()
+            if d:
+                x = np.nextafter(x, np.inf * d)
+                y = np.nextafter(y, -np.inf * d)
+            cols.append(np.stack([x, y, np.zeros_like(x), np.ones_like(x)]))
+        pc = np.ascontiguousarray(np.concatenate(cols, axis=1))
+        lab = np.tile(np.array(mo.LABEL_COLORS[0], dtype=np.uint8).reshape(3, 1), (1, pc.shape[1]))
+        grid = np.zeros((sm.map_height, sm.map_width, sm.map_depth))
+        sm.update_map(grid, pc, lab)
+        want = np.zeros_like(grid)
+        mo.update_map(want, pc, lab, boundary, res, mo.LABELS_NAMES, mo.LABEL_COLORS, np.eye(5), False)
+        assert np.array_equal(grid, want), "resolution %s" % res
+        assert want.sum() > 1000
+
+
 def test_edge_cases(cuda_device):
     """Empty cloud, a cloud with no survivor, and argument errors reported through avl_last_error."""
     g = np.load(CASES[0])

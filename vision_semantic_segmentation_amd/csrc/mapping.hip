@@ -78,6 +78,30 @@ __device__ __forceinline__ int cvt_i32_numpy(double v) {
     return (int)v;
 }
 
+// int32(num / den) exactly as NumPy computes it -- the correctly rounded float64 quotient, truncated (cvt_i32_numpy) -- without
+// the ~35-instruction IEEE division sequence in the common case (round 4; four divisions per point).  `y` approximates 1 / den to
+// a few ulp (refine_rcp).  q = num * y corrected once by its own residual is within ~2 ulp of the true quotient; the truncation of
+// that equals the truncation of the correctly rounded quotient unless an integer lies within those ulps -- so lanes whose q is
+// within 2^-44 (relative) of an integer, or is not an ordinary number (NaN, infinity, zero, |q| >= 2^40: zero / non-finite
+// denominators, overflow), take the exact division instead.  Both paths give the same int32 for every input; the exact one runs
+// for ~1e-10 of ordinary points (tests/test_gpu_mapping.py::test_truncating_divisions_on_integer_boundaries forces it).
+__device__ __forceinline__ double refine_rcp(double den) {
+    double y = __builtin_amdgcn_rcp(den);                 // v_rcp_f64: ~26 bits
+    double e = __builtin_fma(-den, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-den, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ int div_i32_numpy(double num, double den, double y) {
+    double q = num * y;
+    const double r = __builtin_fma(-q, den, num);
+    q = __builtin_fma(r, y, q);
+    const double aq = __builtin_fabs(q);
+    const bool safe = __builtin_fabs(q - __builtin_rint(q)) > aq * 0x1p-44 && aq > 0x1p-500 && aq < 0x1p40;
+    if (!safe) q = num / den;
+    return cvt_i32_numpy(q);
+}
+
 // dot of a 4-vector row with (a,b,c,d) in OpenBLAS's order: r0*a, then fma chain.
 __device__ __forceinline__ double dot4(const double* r, double a, double b, double c, double d) {
     double s = r[0] * a;
@@ -98,8 +122,9 @@ __device__ __forceinline__ bool project(const ProjParams& pp, double x, double y
     const double p0 = dot4(pp.P + 0, v0, v1, v2, v3);
     const double p1 = dot4(pp.P + 4, v0, v1, v2, v3);
     const double p2 = dot4(pp.P + 8, v0, v1, v2, v3);
-    ix = cvt_i32_numpy(p0 / p2);
-    iy = cvt_i32_numpy(p1 / p2);
+    const double rp2 = refine_rcp(p2);
+    ix = div_i32_numpy(p0, p2, rp2);
+    iy = div_i32_numpy(p1, p2, rp2);
     const bool positive = (0.0 < v0) && (v0 < pp.range_max);
     return positive && ix >= 0 && ix < pp.img_w && iy >= 0 && iy < pp.img_h;
 }
@@ -109,8 +134,9 @@ __device__ __forceinline__ int grid_cell(const GridParams& g, double x, double y
     const double xl = x + g.off_x, yl = y + g.off_y, zl = z + 0.0;
     // :406 subtracts 0*z-like terms built from every coordinate: one non-finite coordinate makes both NaN
     if (!(__builtin_isfinite(xl) && __builtin_isfinite(yl) && __builtin_isfinite(zl))) return -1;
-    const int cx = cvt_i32_numpy((xl - g.b00) / g.resolution);
-    const int cy = cvt_i32_numpy((yl - g.b10) / g.resolution);
+    const double rres = refine_rcp(g.resolution);
+    const int cx = div_i32_numpy(xl - g.b00, g.resolution, rres);
+    const int cy = div_i32_numpy(yl - g.b10, g.resolution, rres);
     if (cx < 0 || cx >= g.Hm || cy < 0 || cy >= g.Wm) return -1;
     return cx * g.Wm + cy;
 }
@@ -467,11 +493,14 @@ __global__ void __launch_bounds__(kBlock) k_grid_apply_lists(MapT* __restrict__ 
 // are compacted into an LDS list (local cell index << 8 | bits) with one LDS atomic each, the mask bytes are cleared,
 // and then ALL lanes apply one listed cell each: the grid rows are read, updated in the reference's class order
 // (class i, then its lane bonus) and written back with every lane busy and every load independent.
-constexpr int kSweepVec = 4;                                  // 16-byte mask vectors per lane and round
-constexpr int kSweepCells = kBlock * kSweepVec * 16;          // cells per workgroup round (16384)
-template <typename MapT>
+// Cells per workgroup round: a camera frustum puts most touched cells into a few grid rows, and the sweep ends when its BUSIEST
+// workgroup does -- 4096-cell rounds (one 16-byte mask vector per lane) instead of 16384: config E 38.4 -> 34.6 us per frame
+// (profiles/r04/mapping_sweep_chunk_ab.log; AVL_SWEEP_VEC = 4 / 2 / 1 in the experiments build).
+constexpr int kSweepVecDefault = 1;
+template <typename MapT, int kSweepVec>                       // 16-byte mask vectors per lane and round: 4 / 2 / 1 -> 16384 / 8192 / 4096 cells
 __global__ void __launch_bounds__(kBlock) k_grid_sweep_bytes(MapT* __restrict__ map, int C, unsigned bonus_classes, CmParams cm,
                                                              unsigned char* __restrict__ mask, long long ncell, int exp) {
+    constexpr int kSweepCells = kBlock * kSweepVec * 16;      // cells per workgroup round
     __shared__ unsigned list[kSweepCells];
     __shared__ int count;
     const long long rounds = (ncell + kSweepCells - 1) / kSweepCells;
@@ -747,14 +776,32 @@ int launch_sweep_bytes(const avl_grid* g, const double* cm_host, unsigned bonus,
     memset(&cm, 0, sizeof(cm));
     memcpy(cm.cm, cm_host, sizeof(double) * g->C * g->C);
     const long long ncell = (long long)g->Hm * g->Wm;
-    const long long rounds = (ncell + kSweepCells - 1) / kSweepCells;
-    const unsigned blocks = (unsigned)(rounds < 2048 ? rounds : 2048);
     unsigned char* mask = reinterpret_cast<unsigned char*>(g->cell_mask);
     const int exp = AVL_EXP_INT("AVL_SWEEP_EXP", 0);      // timing experiments only (experiments build; 0 in the release library)
-    if (g->map_dtype == AVL_F64)
-        hipLaunchKernelGGL(k_grid_sweep_bytes<double>, dim3(blocks), dim3(kBlock), 0, s, static_cast<double*>(g->map), g->C, bonus, cm, mask, ncell, exp);
-    else
-        hipLaunchKernelGGL(k_grid_sweep_bytes<float>, dim3(blocks), dim3(kBlock), 0, s, static_cast<float*>(g->map), g->C, bonus, cm, mask, ncell, exp);
+#ifdef AVL_EXPERIMENTS
+    const int vec = AVL_EXP_INT("AVL_SWEEP_VEC", kSweepVecDefault);
+#else
+    constexpr int vec = kSweepVecDefault;
+#endif
+#define AVL_SWEEP_LAUNCH(T, V)                                                                                                        \
+    do {                                                                                                                              \
+        const long long rounds = (ncell + kBlock * V * 16 - 1) / (kBlock * V * 16);                                                   \
+        const unsigned blocks = (unsigned)(rounds < 8192 ? rounds : 8192);                                                            \
+        hipLaunchKernelGGL((k_grid_sweep_bytes<T, V>), dim3(blocks), dim3(kBlock), 0, s, static_cast<T*>(g->map), g->C, bonus, cm, mask, ncell, exp); \
+    } while (0)
+    if (g->map_dtype == AVL_F64) {
+#ifdef AVL_EXPERIMENTS
+        if (vec == 4) AVL_SWEEP_LAUNCH(double, 4); else if (vec == 2) AVL_SWEEP_LAUNCH(double, 2); else
+#endif
+            AVL_SWEEP_LAUNCH(double, kSweepVecDefault);
+    } else {
+#ifdef AVL_EXPERIMENTS
+        if (vec == 4) AVL_SWEEP_LAUNCH(float, 4); else if (vec == 2) AVL_SWEEP_LAUNCH(float, 2); else
+#endif
+            AVL_SWEEP_LAUNCH(float, kSweepVecDefault);
+    }
+#undef AVL_SWEEP_LAUNCH
+    (void)vec;
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
