@@ -1339,9 +1339,11 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             for (int j = 0; j < 4; ++j) substep(F16(), j == 3);
             for (int u = 0; u < nmx; ++u) substep(FP4(), u + 1 < nmx);
         }
+        unsigned long long te0 = 0;
+        if (PROBE == 3) te0 = stamp();
         mx_epilogue<IO, MI>(q, acc, nt, mt, wm, wn, fr, kq);
         if (t + nwg < total) init_acc(t + nwg);
-        if (PROBE == 3) tlast = 0;                               // (the epilogue is not part of the sub-step sums)
+        if (PROBE == 3) { tsum[6] += stamp() - te0; tsum[7] += 1; tlast = 0; }      // (the epilogue is not part of the sub-step sums: [6] / [7] = cycles per epilogue)
     }
     if (PROBE == 3 && q.dbg && lane == 0) {
 #pragma unroll
@@ -1671,7 +1673,10 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
     a.g.ntiles = a.g.N / 256;
     const int mtiles = (a.g.M + BM - 1) / BM;
     const int total = mtiles * a.g.ntiles;
-    const int grid = total < 256 ? total : 256;
+    int grid = total < 256 ? total : 256;
+#ifdef AVL_EXPERIMENTS
+    { const int gl = AVL_EXP_INT("AVL_MX_GRID", 0); if (gl > 0 && gl < grid) grid = gl; }      // fewer workgroups: is a phase chip- or CU-bound?
+#endif
     // Which main loop: the software-pipelined stream wins where the K loop is long (K >= 1024: -2...-9 % on layer4 / layer3 conv1
     // and conv3 + downsample), the round-2 kernel (two plain barriers per sub-step, a cheaper tile switch) where a tile is only 1-2 K
     // macro-blocks (K = 256 / 512: layer2, layer3 conv3, the decoder's pointwise convs: the stream is +2...+19 % there);
@@ -1721,8 +1726,9 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
                     for (int i = 0; i < 8; ++i) sum[w >= 4][i] += (double)dbg[(b * 8 + w) * 8 + i];
             for (int e = 0; e < 2; ++e) {
                 const double n = sum[e][5] > 0 ? sum[e][5] : 1;
-                fprintf(stderr, "[mx probe] M %d N %d K %d nmx %d %s waves: cycles per sub-step %.0f | EW wait+barrier %.0f | W burst %.0f | EV wait+barrier %.0f | A burst %.0f\n",
-                        a.g.M, a.g.N, a.g.K, a.nmx, e ? "early (4-7)" : "late (0-3)", sum[e][0] / n, sum[e][1] / n, sum[e][2] / n, sum[e][3] / n, sum[e][4] / n);
+                fprintf(stderr, "[mx probe] M %d N %d K %d nmx %d %s waves: cycles per sub-step %.0f | EW wait+barrier %.0f | W burst %.0f | EV wait+barrier %.0f | A burst %.0f | epilogue %.0f (x %.1f per wave)\n",
+                        a.g.M, a.g.N, a.g.K, a.nmx, e ? "early (4-7)" : "late (0-3)", sum[e][0] / n, sum[e][1] / n, sum[e][2] / n, sum[e][3] / n, sum[e][4] / n,
+                        sum[e][7] > 0 ? sum[e][6] / sum[e][7] : 0., sum[e][7] / (4.0 * grid));
             }
         }
         else if (late_env == L1) AVL_PIPE_LAUNCH(IO, MI, L1);
