@@ -340,3 +340,38 @@ def test_node_with_ros_style_messages_and_two_camera_threads(state, cuda_device)
     # an unknown camera is segmented (no undistortion) but has no publisher (:135-136)
     node.image_callback(msg("camera1", 1).__class__(**dict(vars(msg("camera1", 1)), header=types.SimpleNamespace(stamp=1, frame_id="camera9"))))
     assert len(node.image_pub_cam1.sent) == 12 and len(node.image_pub_cam6.sent) == 12
+
+
+def test_mixed_self_check_for_a_real_checkpoint(state, cuda_device, tmp_path):
+    """the 1e-3 margin of the mixed mode was measured on random-init weights, so a checkpoint loaded through MODEL.WEIGHT
+    (the reference's format: {'model': state_dict} with 'module.' keys, semantic_segmentation.py:31-32) is checked once against the
+    fp32-input HIP path; MIXED_LAYER1_LO (the one speed-for-accuracy option that is off by default) is switched on when the error
+    passes the threshold."""
+    import torch
+    from vision_semantic_segmentation_amd import SemanticSegmentation
+    path = str(tmp_path / "model_best.pth")
+    torch.save({"model": {"module." + k: v for k, v in state.items()}}, path)
+    cfg = _cfg("mixed")
+    cfg.MODEL.WEIGHT = path
+    assert cfg.MODEL.MIXED_SELF_CHECK == "auto" and cfg.MODEL.MIXED_LAYER1_LO is False
+    seg = SemanticSegmentation(cfg, device=cuda_device)
+    assert seg.mixed_check is None
+    img = np.random.default_rng(3).integers(0, 256, size=(320, 416, 3), dtype=np.uint8)
+    labels = seg.segmentation(img)
+    chk = seg.mixed_check
+    print("self-check:", chk)
+    assert chk is not None and chk["size"] == (320, 416) and chk["rel_err"] <= 1e-3 and chk["layer1_lo"] is False
+    assert labels.shape == (76, 100)
+    # the same weights handed over as a state dict (tests, bench): no check unless asked for
+    seg2 = SemanticSegmentation(_cfg("mixed"), device=cuda_device, state_dict=state)
+    seg2.segmentation(img)
+    assert seg2.mixed_check is None
+    # a threshold nothing meets: the lo planes of layer1 are switched on, and the plans built afterwards carry them
+    seg3 = SemanticSegmentation(cfg, device=cuda_device)
+    chk3 = seg3.check_mixed_against_f32(320, 416, threshold=1e-7)
+    assert [t[0] for t in chk3["tried"]] == [False, True]
+    best = min(chk3["tried"], key=lambda t: t[1])
+    assert chk3["layer1_lo"] is best[0] and chk3["rel_err"] == best[1] <= 1e-3
+    n_lo = sum(1 for op in seg3.net_for(320, 416).ops if op.out_lo)
+    n_lo_default = sum(1 for op in seg.net_for(320, 416).ops if op.out_lo)
+    assert (n_lo > n_lo_default) if chk3["layer1_lo"] else (n_lo == n_lo_default)
