@@ -267,7 +267,8 @@ def pmc_traffic(n_gemm_launches, precision):
     --pmc passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
     16-B/lane reads on gfx950).  PMC cannot be collected inside the timed run, so this is read from
     profiles/ (tools/pmc_seg.sh regenerates it); None if no summary for this precision is committed."""
-    for rel in (os.path.join("profiles", "r03", "pmc_seg_summary_%s.json" % precision),
+    for rel in (os.path.join("profiles", "r04", "pmc_seg_summary_%s.json" % precision),
+                os.path.join("profiles", "r03", "pmc_seg_summary_%s.json" % precision),
                 os.path.join("profiles", "r02", "pmc_seg_summary_%s.json" % precision),
                 os.path.join("profiles", "r01", "pmc_seg_summary.json") if precision == "bf16" else None):
         if rel and os.path.exists(os.path.join(ROOT, rel)):
