@@ -977,6 +977,7 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
     constexpr int NS = 2 * MI, D = 3, EV = NS - D;              // steps per sub-step; fragments are read D steps ahead; the (main) event sits in front of step EV
     constexpr int EW = MI == 8 ? 5 : EV;                         // ... and the weight-slot event (MI = 4: one event for both slots)
     constexpr bool SPR = SPREAD == 1 || SPREAD == 2, PIN = SPREAD != 0;     // experiments: DMA schedules 1 / 2; 3 = the release schedule with pinned MFMAs
+    constexpr bool MID = SPREAD == 4;       // experiment: waves 0-3 send their bursts in the MIDDLE between two events (steps 1 / 9) instead of in front of the next one
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const GemmArgs& p = q.g;
 
@@ -1180,7 +1181,7 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
         if (EW != EV && S == EW) {
             // complementary bursts: waves 0-3 send the ACTIVATION tile of the sub-step after next here, one event after waves 4-7
             // did (its slot was released at the previous main event; not in the very first sub-step: that tile is already in flight)
-            if (!SPR && LATE == 0 && !early && g > 0 && PROBE != 1 && pt < total) {
+            if (!SPR && !MID && LATE == 0 && !early && g > 0 && PROBE != 1 && pt < total) {
                 unsigned long long t1 = 0;
                 if (PROBE == 3) t1 = stamp();
                 issue_a();
@@ -1209,7 +1210,7 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             // every read of this slot was issued >= 2 steps ago.  DMA: the only operations this wave may still have in flight
             // are the W_INSTR of the weight burst it issued a few steps ago (for the sub-step after next); everything older
             // -- both tiles of the next sub-step, epilogue stores -- is waited for
-            if (!SPR && EW != EV && LATE == 0 && !early && PROBE != 1 && pt < total) {
+            if (!SPR && !MID && EW != EV && LATE == 0 && !early && PROBE != 1 && pt < total) {
                 unsigned long long t1 = 0;
                 if (PROBE == 3) t1 = stamp();
                 issue_w();
@@ -1243,6 +1244,14 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             if (EW == EV) issue_w();
             issue_a();
             if (PROBE == 3) tsum[4] += stamp() - t1;
+        }
+        if constexpr (MID) {
+            // whole bursts, four steps behind those of waves 4-7 (which send right behind the events at steps 5 / 13): the weight tile of
+            // sub-step g + 2 at step 9 (its slot was released at EW, step 5), the activation tile of sub-step g + 1 at step 1 (slot
+            // released at the previous EV).  Same order per wave (weights, activations), so the counts at the events stand.
+            static_assert(MI == 8 && EW == 5 && EV == 13, "MID: 16-step sub-steps only");
+            if constexpr (S == 9) { if (!early && pt < total) { issue_w(); w_sent = true; } }
+            if constexpr (S == 1) { if (!early && g > 0 && pt < total) issue_a(); }
         }
         if constexpr (SPR) {
             // SPREAD: no bursts.  Every step, one wave of each SIMD sends ONE DMA instruction: waves 4-7 on the odd steps, waves 0-3
@@ -1735,6 +1744,7 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
         else if (MI == 8 && AVL_EXP_INT("AVL_MX_SPREAD", 0) == 1) AVL_PIPE_LAUNCH(IO, 8, 0, 0, 1);
         else if (MI == 8 && AVL_EXP_INT("AVL_MX_SPREAD", 0) == 2) AVL_PIPE_LAUNCH(IO, 8, 0, 0, 2);
         else if (MI == 8 && AVL_EXP_INT("AVL_MX_SPREAD", 0) == 3) AVL_PIPE_LAUNCH(IO, 8, 0, 0, 3);
+        else if (MI == 8 && AVL_EXP_INT("AVL_MX_SPREAD", 0) == 4) AVL_PIPE_LAUNCH(IO, 8, 0, 0, 4);
         else
 #endif
             AVL_PIPE_LAUNCH(IO, MI, L0);
