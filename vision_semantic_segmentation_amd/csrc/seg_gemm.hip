@@ -589,6 +589,7 @@ struct MxArgs {
     long long a_srows2;
     int stagger;                // 1: waves 0-3 issue their LDS-DMAs after the first K half of a sub-step (A/B switch)
     unsigned long long* dbg;    // AVL_MX_PROBE=3 only: per-wave cycle sums (host-visible memory), else NULL
+    int same_tile;              // AVL_MX_PROBE=3 + AVL_MX_SAMETILE=1 (experiments): all workgroups load tile (0, 0): what would an all-hits K loop take?
 };
 
 // 16 values of one lane + the 16 of its partner (lane ^ 16) form one MX block: shared E8M0 scale, e2m1 elements.
@@ -962,7 +963,7 @@ __global__ void __launch_bounds__(512) k_gemm_ring_mx(MxArgs q, int mtiles) {
 // PROBE (timing experiments, results are garbage): 1 = no DMA after the prologue, 2 = no MFMAs, 3 = s_memtime stamps around the
 // events and the DMA bursts, per-wave sums -> q.dbg (each stamp drains the LDS queue: read the SHARES, not the totals),
 // 4 = no weight-fragment LDS reads after the first two sub-steps (a third of the LDS read bytes), 5 = every other activation
-// fragment not read (another third)
+// fragment not read (another third), 6 = every other DMA instruction not sent (half the staging bytes: throughput- or latency-bound?)
 template <int IO, int MI, int LATE, int PROBE = 0, int SPREAD = 0>
 __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
     typedef f16 H;
@@ -1035,8 +1036,9 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
         pmbl = 0;
     };
     auto set_tile = [&]() __attribute__((always_inline)) {                  // rare: once per tile
-        const int nt_ = pt % ntiles;
+        int nt_ = pt % ntiles;
         p_mt = pt / ntiles;
+        if (PROBE == 3 && q.same_tile) { nt_ = 0; p_mt = 0; }   // probe (results garbage): every workgroup streams THE SAME tiles = all L2 hits
         cur_w16 = static_cast<const char*>(p.W) + (long long)nt_ * BN * p.K * 2;
         cur_wq = q.Wq[0] + (long long)nt_ * BN * (p.K / 2);
         cur_ws = q.Ws[0] + (long long)nt_ * BN * 8;
@@ -1057,13 +1059,13 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             const unsigned wl = wr0 * (unsigned)(p.K * 2) + cw;
 #pragma unroll
             for (int i = 0; i < W_INSTR; ++i)
-                if (only < 0 || only == i) glds16_saddr(sw + (long long)i * (NW * 8) * p.K * 2, wl, wbase + i * NW * 1024);
+                if ((only < 0 || only == i) && !(PROBE == 6 && (i & 1))) glds16_saddr(sw + (long long)i * (NW * 8) * p.K * 2, wl, wbase + i * NW * 1024);
         } else {
             const char* sw = cur_wq + (pj == 4 ? 0 : cur_wps) + (long long)pmb * 128;
             const unsigned wl = wr0 * (unsigned)(p.K / 2) + cw;
 #pragma unroll
             for (int i = 0; i < W_INSTR; ++i)
-                if (only < 0 || only == i) glds16_saddr(sw + (long long)i * (NW * 8) * (p.K / 2), wl, wbase + i * NW * 1024);
+                if ((only < 0 || only == i) && !(PROBE == 6 && (i & 1))) glds16_saddr(sw + (long long)i * (NW * 8) * (p.K / 2), wl, wbase + i * NW * 1024);
         }
     };
     // (the last piece also brings the scale blocks of an FP4 sub-step and moves the producer on to the next sub-step)
@@ -1075,14 +1077,14 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             const unsigned al = srow * (unsigned)cur_rowb16 + ct;
 #pragma unroll
             for (int i = 0; i < A_INSTR; ++i)
-                if (only < 0 || only == i) glds16_saddr(sa + (long long)i * (NW * 8) * cur_rowb16, al, abase + i * NW * 1024);
+                if ((only < 0 || only == i) && !(PROBE == 6 && (i & 1))) glds16_saddr(sa + (long long)i * (NW * 8) * cur_rowb16, al, abase + i * NW * 1024);
         } else {
             const long long ta = pj == 4 ? 0 : cur_aps, tw = pj == 4 ? 0 : cur_wps;     // which correction pass
             const char* sa = cur_aq + ta + (long long)pmbl * 128;
             const unsigned a_lq = srow * (unsigned)cur_rowbq + ct;
 #pragma unroll
             for (int i = 0; i < A_INSTR; ++i)
-                if (only < 0 || only == i) glds16_saddr(sa + (long long)i * (NW * 8) * cur_rowbq, a_lq, abase + i * NW * 1024);
+                if ((only < 0 || only == i) && !(PROBE == 6 && (i & 1))) glds16_saddr(sa + (long long)i * (NW * 8) * cur_rowbq, a_lq, abase + i * NW * 1024);
             // scales: BM x 8 bytes for the activation rows (waves 0, 1: one KB each), 2 KB for the weight rows (waves 2, 3)
             if ((only < 0 || only == A_INSTR - 1) && wave < 4 && (wave >= 2 || wave * 128 < BM)) {
                 const char* ss = wave < 2 ? cur_as + ta + (long long)pmbl * cur_asrows * 8 + wave * 1024
@@ -1220,7 +1222,7 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             // (no weight burst once the work has run out: then nothing may stay in flight)
             unsigned long long t0 = 0;
             if (PROBE == 3) t0 = stamp();
-            if (EW != EV && w_sent) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(W_INSTR) : "memory");
+            if (EW != EV && w_sent) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(PROBE == 6 ? W_INSTR / 2 : W_INSTR) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             w_sent = false;
             __builtin_amdgcn_sched_barrier(0);
@@ -1679,6 +1681,7 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
     constexpr int BM = 2 * MI * 16, LDS = 2 * (BM + 256) * 128 + 2 * 4096;
     MxArgs a = a0;
     a.stagger = AVL_EXP_INT("AVL_MX_STAGGER", 1);
+    a.same_tile = 0;
     a.g.ntiles = a.g.N / 256;
     const int mtiles = (a.g.M + BM - 1) / BM;
     const int total = mtiles * a.g.ntiles;
@@ -1719,6 +1722,7 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
         else if (MI == 8 && probe == 2) AVL_PIPE_LAUNCH(IO, 8, 0, 2);
         else if (MI == 8 && probe == 4) AVL_PIPE_LAUNCH(IO, 8, 0, 4);
         else if (MI == 8 && probe == 5) AVL_PIPE_LAUNCH(IO, 8, 0, 5);
+        else if (MI == 8 && probe == 6) AVL_PIPE_LAUNCH(IO, 8, 0, 6);
         else if (MI == 8 && probe == 3) {
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             AVL_HIP_CHECK(hipStreamIsCapturing(s, &cap));
@@ -1727,6 +1731,7 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
             if (!dbg) AVL_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&dbg), 256 * 8 * 8 * sizeof(unsigned long long), 0));
             memset(dbg, 0, 256 * 8 * 8 * sizeof(unsigned long long));
             a.dbg = dbg;
+            a.same_tile = AVL_EXP_INT("AVL_MX_SAMETILE", 0);
             AVL_PIPE_LAUNCH(IO, 8, 0, 3);
             AVL_HIP_CHECK(hipStreamSynchronize(s));
             double sum[2][8] = {};
