@@ -976,8 +976,9 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
     constexpr int S_BYTES = 4096;
     constexpr int A_INSTR = BM / 8 / NW, W_INSTR = BN / 8 / NW;
     constexpr int NS = 2 * MI, D = 3, EV = NS - D;              // steps per sub-step; fragments are read D steps ahead; the (main) event sits in front of step EV
-    constexpr int EW = MI == 8 ? 5 : EV;                         // ... and the weight-slot event (MI = 4: one event for both slots)
+    constexpr int EW = (MI == 8 && SPREAD != 5) ? 5 : EV;        // ... and the weight-slot event (MI = 4: one event for both slots; SPREAD = 5: experiment, one event for MI = 8 too)
     constexpr bool SPR = SPREAD == 1 || SPREAD == 2, PIN = SPREAD != 0;     // experiments: DMA schedules 1 / 2; 3 = the release schedule with pinned MFMAs
+    constexpr bool ONE = SPREAD == 5;       // experiment: ONE event per sub-step (step 13, both slots); waves 4-7 send both tiles right behind it, waves 0-3 at step 5
     constexpr bool MID = SPREAD == 4;       // experiment: waves 0-3 send their bursts in the MIDDLE between two events (steps 1 / 9) instead of in front of the next one
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const GemmArgs& p = q.g;
@@ -1240,18 +1241,21 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
             Wsn = rdWs(sbn);
             readAn(0);
         }
-        if (!SPR && PROBE != 1 && !early && (EW == EV || LATE != 0) && S == EV + LATE && pt < total) {
+        if (!SPR && !ONE && PROBE != 1 && !early && (EW == EV || LATE != 0) && S == EV + LATE && pt < total) {
             unsigned long long t1 = 0;
             if (PROBE == 3) t1 = stamp();
             if (EW == EV) issue_w();
             issue_a();
             if (PROBE == 3) tsum[4] += stamp() - t1;
         }
+        if constexpr (ONE) {
+            if constexpr (S == 5) { if (!early && g > 0 && pt < total) { issue_w(); issue_a(); } }
+        }
         if constexpr (MID) {
             // whole bursts, four steps behind those of waves 4-7 (which send right behind the events at steps 5 / 13): the weight tile of
             // sub-step g + 2 at step 9 (its slot was released at EW, step 5), the activation tile of sub-step g + 1 at step 1 (slot
             // released at the previous EV).  Same order per wave (weights, activations), so the counts at the events stand.
-            static_assert(MI == 8 && EW == 5 && EV == 13, "MID: 16-step sub-steps only");
+            static_assert(MI == 8 && EV == 13, "MID: 16-step sub-steps only");
             if constexpr (S == 9) { if (!early && pt < total) { issue_w(); w_sent = true; } }
             if constexpr (S == 1) { if (!early && g > 0 && pt < total) issue_a(); }
         }
@@ -1750,6 +1754,7 @@ int launch_ring_mx_t(const MxArgs& a0, hipStream_t s) {
         else if (MI == 8 && AVL_EXP_INT("AVL_MX_SPREAD", 0) == 2) AVL_PIPE_LAUNCH(IO, 8, 0, 0, 2);
         else if (MI == 8 && AVL_EXP_INT("AVL_MX_SPREAD", 0) == 3) AVL_PIPE_LAUNCH(IO, 8, 0, 0, 3);
         else if (MI == 8 && AVL_EXP_INT("AVL_MX_SPREAD", 0) == 4) AVL_PIPE_LAUNCH(IO, 8, 0, 0, 4);
+        else if (MI == 8 && AVL_EXP_INT("AVL_MX_SPREAD", 0) == 5) AVL_PIPE_LAUNCH(IO, 8, 0, 0, 5);
         else
 #endif
             AVL_PIPE_LAUNCH(IO, MI, L0);
