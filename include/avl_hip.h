@@ -241,6 +241,17 @@ int avl_eval_map(const uint8_t* color_map, int H, int W, const uint8_t* mask, in
                                 tap pairs of the hi parts, five of the lo parts, the fp32 bias; then the tile order as
                                 above.  `weight` is the 1x1 conv's [n][K/64][hi 64 | lo 64] as for w_split = 1. */
 
+#define AVL_OP_BOTTLENECK 12 /* one torchvision Bottleneck of layer1 (backbone/resnet.py:24-43; stride 1, dilation 1, width 128 -> 256
+                                channels) in ONE kernel, AVL_F16 "mixed" precision: conv1 1x1 +b+ReLU -> grouped 3x3 (32 groups, pad 1)
+                                +b+ReLU -> conv3 1x1 +b (+ identity | + downsample 1x1) -> ReLU; the two intermediates live in LDS.
+                                in (+ in_lo: enters the residual sum only) = block input, in_c = 256 (identity residual, w_layout 0)
+                                or 64 (the block's downsample 1x1 runs as extra K steps of conv3: w_layout 1); out (+ out_lo).
+                                Weights are f16 pairs hi + lo in MFMA FRAGMENT order ([...][hi, lo][lane 64][8], network.pack_bottleneck):
+                                weight = conv1 [n 8][ks in_c/32], in2 = the 3x3 as block-diagonal 16-channel windows [window 8][ks 5]
+                                (K = 32 = two taps x 16 channels), in3 = conv3 [wave 8][ks 4 (+ in_c/32 downsample steps)][nj 2];
+                                in3_c = 128 (the width); bias = fp32 [b1 128 | b2 128 | b3 256 (+ downsample bias)].
+                                w_split = 1 (in_c = 64 only): conv1's result keeps a lo plane in LDS (conv2 runs a third pass). */
+
 typedef struct avl_seg_op {
     int32_t kind;            /* AVL_OP_*                                                        */
     int32_t dtype;           /* activation type of in/in2/out: AVL_BF16, AVL_F16 or AVL_F32      */

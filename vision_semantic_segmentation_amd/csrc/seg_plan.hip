@@ -17,6 +17,7 @@ int validate(const avl_seg_op& op, int index) {
     int rc;
     if (op.kind == AVL_OP_GEMM) rc = validate_gemm(op);
     else if (op.kind == AVL_OP_DWPW) rc = validate_dwpw(op);
+    else if (op.kind == AVL_OP_BOTTLENECK) rc = validate_bottleneck(op);
     else rc = validate_conv_op(op);
     if (rc != AVL_OK) {
         char msg[400];
@@ -29,6 +30,7 @@ int validate(const avl_seg_op& op, int index) {
 int launch(const avl_seg_op& op, hipStream_t s) {
     if (op.kind == AVL_OP_GEMM) return launch_gemm(op, s);
     if (op.kind == AVL_OP_DWPW) return launch_dwpw(op, s);
+    if (op.kind == AVL_OP_BOTTLENECK) return launch_bottleneck(op, s);
     return launch_conv_op(op, s);
 }
 
@@ -77,6 +79,15 @@ void work(const avl_seg_op& op, double& flops, double& bytes) {
         case AVL_OP_BILINEAR:
             flops = 8.0 * out_pix * op.out_c;
             break;
+        case AVL_OP_BOTTLENECK: {
+            // the three convolutions (+ the downsample 1x1) on the image's own pixels: halo recomputation is not algorithmic work;
+            // bytes: input once, output once, weights once -- the intermediates never exist in memory
+            const double width = op.in3_c, cg = width / op.groups;
+            const double macs = op.in_c * width + width * cg * 9 + width * op.out_c + (op.w_layout ? (double)op.in_c * op.out_c : 0.0);
+            flops = 2.0 * out_pix * macs;
+            bytes += 2.0 * es * macs;
+            break;
+        }
         case AVL_OP_GAP:
             flops = in_pix * op.in_c;
             bytes = in_pix * op.in_c * es;

@@ -160,5 +160,7 @@ int validate_gconv_mfma(const avl_seg_op& op);
 int launch_stem_mfma(const avl_seg_op& op, hipStream_t s);
 int launch_dwpw(const avl_seg_op& op, hipStream_t s);
 int validate_dwpw(const avl_seg_op& op);
+int launch_bottleneck(const avl_seg_op& op, hipStream_t s);
+int validate_bottleneck(const avl_seg_op& op);
 
 }  // namespace avl

@@ -27,8 +27,9 @@ from . import _lib
 
 BN_EPS = 1e-5
 
-OP_STEM, OP_MAXPOOL, OP_GEMM, OP_GCONV, OP_DWCONV, OP_BILINEAR, OP_GAP, OP_GEMV, OP_ARGMAX, OP_SUBSAMPLE, OP_DWPW = range(1, 12)
-OP_NAMES = {1: "stem", 2: "maxpool", 3: "gemm", 4: "gconv", 5: "dwconv", 6: "bilinear", 7: "gap", 8: "gemv", 9: "argmax", 10: "subsample", 11: "dwpw"}
+OP_STEM, OP_MAXPOOL, OP_GEMM, OP_GCONV, OP_DWCONV, OP_BILINEAR, OP_GAP, OP_GEMV, OP_ARGMAX, OP_SUBSAMPLE, OP_DWPW, OP_BOTTLENECK = range(1, 13)
+OP_NAMES = {1: "stem", 2: "maxpool", 3: "gemm", 4: "gconv", 5: "dwconv", 6: "bilinear", 7: "gap", 8: "gemv", 9: "argmax", 10: "subsample", 11: "dwpw",
+            12: "bottleneck"}
 
 
 class AvlSegOp(C.Structure):
@@ -319,6 +320,52 @@ def pack_split_rows(w, nsub):
     return torch.cat(parts, dim=2).reshape(rows, k * nsub).contiguous()
 
 
+def _mfma_a_fragments(m):
+    """float16 [rows % 16 == 0][K % 32 == 0] -> [rows/16][K/32][lane 64][8]: the A operand of v_mfma_f32_16x16x32_f16 as one wave
+    loads it (lane l holds row l & 15, K values 8 (l >> 4) .. + 7 of the 32-wide step): 1 KB contiguous per fragment."""
+    rows, k = m.shape
+    return m.reshape(rows // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(rows // 16, k // 32, 64, 8)
+
+
+def pack_bottleneck(w1, w2, w3, wd, groups):
+    """Weights of AVL_OP_BOTTLENECK (seg_bottleneck.hip), every one as an f16 pair hi + lo in MFMA fragment order:
+      conv1  float64 [width][cin]            -> [n width/16][ks cin/32][hi, lo][lane][8]
+      conv2  float64 [width][width/groups][3][3] -> block-diagonal 16-channel windows, K = 32 = two taps x 16 input channels:
+             [window width/16][ks 5][hi, lo][lane][8]; K value 8 kq + j of step ks is tap 2 ks + (kq >> 1) (the tenth is zero),
+             input channel (kq & 1) * 8 + j of the window
+      conv3  float64 [cout][width] (+ downsample [cout][cin] or None as extra K steps) -> [wave cout/32][ks][nj 2][hi, lo][lane][8];
+             MFMA row i of n-tile nj is output channel 32 wave + (i >> 2) * 8 + nj * 4 + (i & 3) (a lane then owns 8 consecutive channels)
+    -> three flat float16 tensors."""
+    width, cin = w1.shape
+    cout = w3.shape[0]
+    cg = width // groups
+    assert width % 16 == 0 and cin % 32 == 0 and cout % 32 == 0 and 16 % cg == 0
+
+    def pair(m):          # [.., lane, 8] hi and lo fragments interleaved as [..][2][lane][8]
+        hi, lo = split_f16(m)
+        return torch.stack([_mfma_a_fragments(hi), _mfma_a_fragments(lo)], dim=2)
+
+    p1 = pair(w1.to(torch.float64))                                                   # [n][ks][2][64][8]
+    # conv2: dense [window][out 16][tap 10][in 16]
+    nwin = width // 16
+    dense = torch.zeros((nwin, 16, 10, 16), dtype=torch.float64)
+    wt = w2.reshape(width, cg, 9).to(torch.float64)
+    co = torch.arange(width)
+    win, col = co // 16, co % 16
+    gbase = (col // cg) * cg
+    for ci in range(cg):
+        dense[win, col, :9, gbase + ci] = wt[co, ci, :]
+    p2 = pair(dense.reshape(nwin * 16, 160))                                          # K = tap * 16 + in: step ks = taps 2 ks, 2 ks + 1
+    # conv3 (+ downsample): rows permuted per 32-channel wave block
+    w3k = w3.to(torch.float64) if wd is None else torch.cat([w3.to(torch.float64), wd.to(torch.float64)], dim=1)
+    i = torch.arange(16)
+    rows = torch.cat([32 * wv + (i >> 2) * 8 + nj * 4 + (i & 3) for wv in range(cout // 32) for nj in range(2)])
+    p3 = pair(w3k[rows])                                                              # [wave * 2 + nj][ks][2][64][8]
+    ks3 = w3k.shape[1] // 32
+    p3 = p3.reshape(cout // 32, 2, ks3, 2, 64, 8).permute(0, 2, 1, 3, 4, 5)            # [wave][ks][nj][2][64][8]
+    return p1.reshape(-1).contiguous(), p2.reshape(-1).contiguous(), p3.reshape(-1).contiguous()
+
+
 _FP4_GRID = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0], dtype=torch.float64)
 
 
@@ -411,7 +458,7 @@ class SegNet(object):
     native plan.  ``forward(image_u8_cuda)`` runs it; ``labels`` / ``logits`` are views of its outputs."""
 
     ROW_PAD = 256        # GEMM tiles read whole 128/256-row tiles
-    MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx", "dw_exact", "layer1_lo")    # keyword switches of the "mixed" mode
+    MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx", "dw_exact", "layer1_lo", "fuse_block")    # keyword switches of the "mixed" mode
 
     def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8, fuse_dwpw=True, raw_frame=None,
                  **mixed_opts):
@@ -446,6 +493,9 @@ class SegNet(object):
         # decoder's low-level branch and layer2 read it).  layer1's GEMMs are HBM-bound (K = 128 / 256 at 129 600 pixels): the lo planes
         # are 0.4 GB of the frame's traffic = 2.5 % of its time, for -10...-30 % logits error (8.2e-4 -> 7.3e-4 on the worst draw)
         self.mixed_layer1_lo = mixed_opts.get("layer1_lo", False)
+        # fuse_block (default): every Bottleneck of layer1 is ONE kernel (AVL_OP_BOTTLENECK: conv1 -> grouped 3x3 -> conv3 + residual with
+        # both intermediates in LDS); False = the three-launch form of rounds 1-4
+        self.mixed_fuse_block = self.mixed and mixed_opts.get("fuse_block", True)
         self.mixed_gconv_mx = mixed_opts.get("gconv_mx", True)   # grouped conv with FP4 corrections for its weights AND for conv1's output (-10..-30 % logits error, -5 % frames/s)
         self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "mixed": torch.float16}[precision]
         self.avl_dtype = {"bf16": _lib.AVL_BF16, "f16": _lib.AVL_F16, "f32": _lib.AVL_F32, "mixed": _lib.AVL_F16}[precision]
@@ -589,6 +639,24 @@ class SegNet(object):
         f["mx_flags"] = flags
         self._op(name, OP_GEMM, **f)
 
+    def _bottleneck(self, p, st, x, hw, cin, width, cout, y):
+        """One Bottleneck (stride 1, dilation 1) as AVL_OP_BOTTLENECK: BN folded, weights as f16 pairs in fragment order."""
+        w1, b1 = fold_bn(st, p + ".conv1.weight", p + ".bn1")
+        w2, b2 = fold_bn(st, p + ".conv2.weight", p + ".bn2")
+        w3, b3 = fold_bn(st, p + ".conv3.weight", p + ".bn3")
+        wd = None
+        if (p + ".downsample.0.weight") in st:
+            wd, bd = fold_bn(st, p + ".downsample.0.weight", p + ".downsample.1")
+            wd, b3 = wd.reshape(cout, cin), b3 + bd
+        p1, p2, p3 = (self._dev(t, torch.float16) for t in pack_bottleneck(w1.reshape(width, cin), w2, w3.reshape(cout, width), wd, GROUPS))
+        bias = self._dev(torch.cat([b1, b2, b3]), torch.float32)
+        ip, ild, irows = self._view(x)
+        op_, old, orows = self._view(y)
+        self._op(p, OP_BOTTLENECK, in_=ip, in_lo=self._lo(x), out=op_, out_lo=self._lo(y), weight=p1.data_ptr(), in2=p2.data_ptr(), in3=p3.data_ptr(),
+                 in3_c=width, bias=bias.data_ptr(), in_h=hw[0], in_w=hw[1], in_c=cin, in_ld=ild, in_rows=irows, out_h=hw[0], out_w=hw[1],
+                 out_c=cout, out_ld=old, out_rows=orows, ksize=3, stride=1, pad=1, dil=1, groups=GROUPS, relu=1, w_layout=int(wd is not None),
+                 w_split=int(wd is not None))
+
     def _dwpw(self, name, src, hw, cin, w_dw, b_dw, w_pw, b_pw, dst, dst_col, dilation, padding=None):
         """DepthwiseSeparableConv2d (3x3 depthwise dil d pad p + BN + ReLU, 1x1 + BN + ReLU) as one op."""
         h, wd = hw
@@ -682,6 +750,14 @@ class SegNet(object):
                 s = stride if bi == 0 else 1
                 d = previous_dilation if bi == 0 else dilation
                 ohw = ((hw[0] + 2 * d - 2 * d - 1) // s + 1, (hw[1] + 2 * d - 2 * d - 1) // s + 1)
+                if (self.mixed_fuse_block and s == 1 and d == 1 and width == 128 and cout == 256 and cin in (64, 256)
+                        and ((p + ".downsample.0.weight") in st) == (cin == 64) and x.hi.shape[1] == cin and (cin == 256 or x.lo is None)):
+                    y = self._act(ohw[0] * ohw[1], cout, split=trunk_lo)
+                    self._bottleneck(p, st, x, hw, cin, width, cout, y)
+                    if x is not low:
+                        self._release(x)
+                    x, hw, cin = y, ohw, cout
+                    continue
                 # conv1 1x1 + bn1 + relu
                 w, b = fold_bn(st, p + ".conv1.weight", p + ".bn1")
                 # where conv1 runs as an MX GEMM its output keeps FP4 copies of both parts (the lo part only so): the grouped conv
