@@ -404,11 +404,13 @@ def test_mixed_logits_with_layer1_lo_planes(state, cuda_device):
         seg = SemanticSegmentation(cfg, device=cuda_device, state_dict=state)
         got = seg.logits(img).cpu()
         net = seg.net_for(320, 416)
-        los.append(sum(1 for n, op in zip(net.op_names, net.ops) if n.startswith("backbone.layer1.") and n.endswith("conv3") and op.out_lo))
+        # (layer1's blocks are one fused op each -- AVL_OP_BOTTLENECK -- named after the block; the three-launch form names conv3)
+        los.append(sum(1 for n, op in zip(net.op_names, net.ops)
+                       if n.startswith("backbone.layer1.") and (n.endswith("conv3") or n.count(".") == 2) and op.out_lo))
         errs.append(float((got - ref).abs().max() / ref.abs().max()))
     print("mixed 320x416: layer1 lo planes off / on: max rel err %.3e / %.3e" % tuple(errs))
     assert los == [1, 3]                       # conv3 outputs of layer1 that carry a lo plane
-    assert errs[0] <= 9e-4 and errs[1] <= errs[0]
+    assert errs[0] <= 9e-4 and errs[1] <= errs[0] * 1.05      # (the fused blocks' conv1 never reads the lo plane: it enters the residual sum only)
 
 
 def _bundle(hi64, lo64, rows_pad):

@@ -153,15 +153,18 @@ __global__ void __launch_bounds__(512) k_bottleneck(BnArgs p) {
             t0 = t;
         }
     };
-    const f16x8* const w1g = reinterpret_cast<const f16x8*>(p.w1) + (size_t)wave * KS1 * 2 * 64 + lane;
-    const f16x8* const w2g = reinterpret_cast<const f16x8*>(p.w2) + (size_t)wave * 5 * 2 * 64 + lane;
-    const f16x8* const w3g = reinterpret_cast<const f16x8*>(p.w3) + (size_t)wave * KS3 * 4 * 64 + lane;
+    // weight fragments by BUFFER loads: wave-uniform resource (SGPRs) + 32-bit lane offset + scalar fragment offset -- per-request 64-bit
+    // VGPR pointers were what hipcc hoisted out of the tile loop and spilled
+    const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.w1)) + (size_t)wave * (KS1 * 2 * 1024), 0, KS1 * 2 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.w2)) + (size_t)wave * (5 * 2 * 1024), 0, 5 * 2 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.w3)) + (size_t)wave * (KS3 * 4 * 1024), 0, KS3 * 4 * 1024, 0x00020000);
+    const int wlane = lane * 16;
+    auto wfrag = [&](__amdgpu_buffer_rsrc_t r, int frag) __attribute__((always_inline)) {
+        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, wlane, frag * 1024, 0));
+    };
     const int ch0 = 32 * wave + 8 * q;                     // conv3: this lane's 8 output channels
-    // conv1's first two K steps of weights are always requested a phase ahead (before the previous tile's last barrier): vmcnt counts
-    // in issue order, a load issued behind the epilogue's stores would wait for them
-    f16x8 w1pre[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) { w1pre[ks][0] = w1g[ks * 128]; w1pre[ks][1] = w1g[ks * 128 + 64]; }
+    // conv1's weights stay in registers for the whole tile (row tiles outside, K steps inside); requested at the top of the tile
+    f16x8 w1f[KS1][2];
 
     for (; tile < p.ntiles; tile += gridDim.x, ++it) {
         const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
@@ -171,48 +174,23 @@ __global__ void __launch_bounds__(512) k_bottleneck(BnArgs p) {
         // the tile loop and spill them)
         int co = c, qo = q;
         asm volatile("" : "+v"(co), "+v"(qo));
-
-        // ================================================= conv1: t1[halo px][16 w ..] = W1 . x      (K steps outside, row tiles inside)
-        f32x4 acc1[BN_M1];
-        f16x8 w2f[5][2];
         const bool more = tile + (int)gridDim.x < p.ntiles;
-        if constexpr (DS) {
-            // two X tiles: the other one is free from the top of the tile on.  conv1's weights are in registers already, the 3x3's are
-            // requested first, so nothing waits behind the DMA burst before conv3's preloads -- a whole conv1 + conv2 later
+        f16x8 w2f[5][2];
 #pragma unroll
-            for (int k2 = 0; k2 < 5; ++k2) { w2f[k2][0] = w2g[k2 * 128]; w2f[k2][1] = w2g[k2 * 128 + 64]; }
-            if (more) stage(tile + gridDim.x, lds0 + ((it & 1) ^ 1) * L::XTILE);
-        }
-        {
-            const float4 b = *reinterpret_cast<const float4*>(p.b1 + 16 * wave + 4 * q);
+        for (int ks = 0; ks < KS1; ++ks) { w1f[ks][0] = wfrag(w1r, 2 * ks); w1f[ks][1] = wfrag(w1r, 2 * ks + 1); }
 #pragma unroll
-            for (int m = 0; m < BN_M1; ++m) acc1[m] = f32x4{b.x, b.y, b.z, b.w};
-            f16x8 wq[3][2];                     // rotating: K step ks in slot ks % 3, requested two steps ahead
-            wq[0][0] = w1pre[0][0]; wq[0][1] = w1pre[0][1]; wq[1][0] = w1pre[1][0]; wq[1][1] = w1pre[1][1];
-#pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                if (ks + 2 < KS1) { wq[(ks + 2) % 3][0] = w1g[(ks + 2) * 128]; wq[(ks + 2) % 3][1] = w1g[(ks + 2) * 128 + 64]; }
-                if (!DS && ks == (KS1 > 2 ? KS1 - 2 : 0)) {      // the 3x3's weights, behind conv1's last weight request
-#pragma unroll
-                    for (int k2 = 0; k2 < 5; ++k2) { w2f[k2][0] = w2g[k2 * 128]; w2f[k2][1] = w2g[k2 * 128 + 64]; }
-                }
-                const f16x8 wh = wq[ks % 3][0], wl = wq[ks % 3][1];
-                const char* xs = X + (ks >> 1) * XSLAB + (x_rd ^ ((ks & 1) << 6));
-#pragma unroll
-                for (int m = 0; m < BN_M1; ++m) {
-                    const f16x8 xb = *reinterpret_cast<const f16x8*>(xs + m * 2048);
-                    acc1[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xb, acc1[m], 0, 0, 0);
-                    acc1[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xb, acc1[m], 0, 0, 0);
-                }
-            }
-        }
-        stamp(0);
+        for (int k2 = 0; k2 < 5; ++k2) { w2f[k2][0] = wfrag(w2r, 2 * k2); w2f[k2][1] = wfrag(w2r, 2 * k2 + 1); }
+        // DS: two X tiles, the other one is free from the top of the tile on; the weight requests above go first, so nothing waits
+        // behind the DMA burst before conv3's preloads -- a whole conv1 + conv2 later
+        if (DS && more) stage(tile + gridDim.x, lds0 + ((it & 1) ^ 1) * L::XTILE);
 
-        // ================================================= t1 -> LDS, conv2 (grouped 3x3 on this wave's own 16-channel window), t2 -> LDS
-        // Output row r of the tile reads halo pixels up to 18 r + 53, i.e. t1 row tiles 0 .. (18 r + 53) / 16: the t1 stores are
-        // interleaved with the rows in program order, so their vector work runs beside the MFMAs of earlier rows.  t2 row r goes IN PLACE
-        // over t1 rows 16 r .. 16 r + 15 of this wave's own channels, which no later output row reads (those start at 18 (r + 1)).
-        auto store_t1 = [&](int m) __attribute__((always_inline)) {
+        // ================================================= conv1 + t1 -> LDS + conv2 + t2 -> LDS as ONE software-pipelined stream
+        // conv1 walks the 12 halo row tiles (K steps inside, weights in registers): the X fragments of row tile m + 1 are read while the 16
+        // MFMAs of tile m run.  Output row r of the 3x3 reads halo pixels up to 18 r + 53, i.e. t1 row tiles 0 .. (18 r + 53) / 16: it is
+        // issued as soon as those are stored, so the 3x3's MFMAs and all the vector work (ReLU, f16 split, masks, LDS addresses) run
+        // beside conv1's MFMAs instead of in a phase of their own.  t2 row r goes IN PLACE over t1 rows 16 r .. 16 r + 15 of this wave's
+        // own channels, which no later output row reads (those start at 18 (r + 1)).
+        auto store_t1 = [&](int m, f32x4 acc) __attribute__((always_inline)) {
             const int h = m * 16 + co;
             const int hy = (h * 3641) >> 16, hx = h - hy * BH_W;
             const int iy = ty * BT_H - 1 + hy, ix = tx * BT_W - 1 + hx;
@@ -221,85 +199,111 @@ __global__ void __launch_bounds__(512) k_bottleneck(BnArgs p) {
             if constexpr (T1LO) {
                 float v[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = relu_f32(acc1[m][k]);
+                for (int k = 0; k < 4; ++k) v[k] = relu_f32(acc[k]);
                 uint2 hi, lo;
                 split4(v, hi, lo);
                 *reinterpret_cast<uint2*>(A + a_wr + m * 4096) = make_uint2(hi.x & vm, hi.y & vm);
                 *reinterpret_cast<uint2*>(A + L::T1LO_OFF + a_wr + m * 4096) = make_uint2(lo.x & vm, lo.y & vm);
             } else {
-                const uint2 hi = relu_pack4(acc1[m]);
+                const uint2 hi = relu_pack4(acc);
                 *reinterpret_cast<uint2*>(A + a_wr + m * 4096) = make_uint2(hi.x & vm, hi.y & vm);
             }
         };
-        f16x8 w3f[KS3][4];
-        uint4 resh[DS ? 1 : BT_H], resl[XLO ? BT_H : 1];
-        static_assert(!(DS && XLO), "the downsample variant has no identity residual");
         uint2 t2lo[T1LO ? 1 : BT_H];                       // no t1 lo plane: the t2 lo plane shares LDS with t1 rows >= 128 -> stored after the last row
-        {
-            const float4 b = *reinterpret_cast<const float4*>(p.b2 + 16 * wave + 4 * q);
-            const unsigned cw16 = (unsigned)(((2 * wave) | (qo & 1)) << 4);
-            unsigned hk[5];
+        const float4 bias1 = *reinterpret_cast<const float4*>(p.b1 + 16 * wave + 4 * q);
+        const float4 bias2 = *reinterpret_cast<const float4*>(p.b2 + 16 * wave + 4 * q);
+        const unsigned cw16 = (unsigned)(((2 * wave) | (qo & 1)) << 4);
+        unsigned hk[5];
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            const int t = min(2 * ks + (qo >> 1), 8);      // this lane's tap in the K step (the tenth "tap" has zero weights)
+            hk[ks] = (unsigned)((t / 3) * BH_W + (t % 3) + co);         // halo pixel of output row 0
+        }
+        auto conv2_row = [&](int r) __attribute__((always_inline)) {
+            f32x4 acc = f32x4{bias2.x, bias2.y, bias2.z, bias2.w};
+            f16x8 th[5], tl[T1LO ? 5 : 1];
 #pragma unroll
             for (int ks = 0; ks < 5; ++ks) {
-                const int t = min(2 * ks + (qo >> 1), 8);  // this lane's tap in the K step (the tenth "tap" has zero weights)
-                hk[ks] = (unsigned)((t / 3) * BH_W + (t % 3) + co);     // halo pixel of output row 0
+                const unsigned h = hk[ks] + 18u * r;
+                const unsigned off = (h << 8) + (cw16 ^ ((h & 15u) << 4));
+                th[ks] = *reinterpret_cast<const f16x8*>(A + off);
+                if constexpr (T1LO) tl[ks] = *reinterpret_cast<const f16x8*>(A + L::T1LO_OFF + off);
             }
-            int next_m = 0;
 #pragma unroll
-            for (int r = 0; r < BT_H; ++r) {
-#pragma unroll
-                for (int m = 0; m < BN_M1; ++m)
-                    if (m >= next_m && m <= (18 * r + 53) / 16) store_t1(m);
-                next_m = (18 * r + 53) / 16 + 1;
-                f32x4 acc = f32x4{b.x, b.y, b.z, b.w};
-#pragma unroll
-                for (int ks = 0; ks < 5; ++ks) {
-                    const unsigned h = hk[ks] + 18u * r;
-                    const unsigned off = (h << 8) + (cw16 ^ ((h & 15u) << 4));
-                    const f16x8 th = *reinterpret_cast<const f16x8*>(A + off);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[ks][0], th, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[ks][1], th, acc, 0, 0, 0);
-                    if constexpr (T1LO) {
-                        const f16x8 tl = *reinterpret_cast<const f16x8*>(A + L::T1LO_OFF + off);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[ks][0], tl, acc, 0, 0, 0);
-                    }
-                }
-                // everything conv3 needs from global memory is requested here, beside the last rows' MFMAs and BEFORE the X DMA of the next
-                // tile goes out: vmcnt counts in issue order, a load behind the DMA burst would wait for the burst's HBM round trip
-                if (r >= BT_H - 4) {
-                    const int g4 = r - (BT_H - 4);
-#pragma unroll
-                    for (int ks = 0; ks < KS3; ++ks)
-                        if (ks * 4 / KS3 == g4) {
-#pragma unroll
-                            for (int f = 0; f < 4; ++f) w3f[ks][f] = w3g[(ks * 4 + f) * 64];
-                        }
-                    if constexpr (!DS) {
-                        // identity: the block input at the tile's own pixels, in accumulator layout (16 B per lane; L2 / MALL hits: the tile was staged from there)
-#pragma unroll
-                        for (int rr = 2 * g4; rr < 2 * g4 + 2; ++rr) {
-                            const int oy = min(ty * BT_H + rr, p.H - 1), ox = min(tx * BT_W + co, p.W - 1);
-                            const unsigned roff = (unsigned)(oy * p.W + ox) * (unsigned)p.in_ld + (unsigned)ch0;
-                            resh[rr] = *reinterpret_cast<const uint4*>(p.x + roff);
-                            if constexpr (XLO) resl[rr] = *reinterpret_cast<const uint4*>(p.x_lo + roff);
-                        }
-                    }
-                }
-                float v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = relu_f32(acc[k]);
-                uint2 hi, lo;
-                split4(v, hi, lo);
-                *reinterpret_cast<uint2*>(A + a_wr + r * 4096) = hi;
-                if constexpr (T1LO) *reinterpret_cast<uint2*>(A + L::T2LO_OFF + a_wr + r * 4096) = lo;
-                else t2lo[r] = lo;
+            for (int ks = 0; ks < 5; ++ks) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[ks][0], th[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[ks][1], th[ks], acc, 0, 0, 0);
+                if constexpr (T1LO) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[ks][0], tl[ks], acc, 0, 0, 0);
             }
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = relu_f32(acc[k]);
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            *reinterpret_cast<uint2*>(A + a_wr + r * 4096) = hi;
+            if constexpr (T1LO) *reinterpret_cast<uint2*>(A + L::T2LO_OFF + a_wr + r * 4096) = lo;
+            else t2lo[r] = lo;
+        };
+        {
+            // X fragment addresses: slab pair (0,1 | 2,3) x K-step parity -> immediate offsets stay below 64 KB
+            const char* xb[KS1 > 4 ? 4 : 2];
+#pragma unroll
+            for (int i = 0; i < (KS1 > 4 ? 4 : 2); ++i) xb[i] = X + (i >> 1) * 2 * XSLAB + (x_rd ^ ((i & 1) << 6));
+            auto read_x = [&](int m, f16x8 (&xf)[KS1]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks)
+                    xf[ks] = *reinterpret_cast<const f16x8*>(xb[(ks >> 2) * 2 + (ks & 1)] + ((ks >> 1) & 1) * XSLAB + m * 2048);
+            };
+            f16x8 xf[2][KS1];
+            read_x(0, xf[0]);
+            int next_row = 0;
+#pragma unroll
+            for (int m = 0; m < BN_M1; ++m) {
+                if (m + 1 < BN_M1) read_x(m + 1, xf[(m + 1) & 1]);
+                f32x4 acc = f32x4{bias1.x, bias1.y, bias1.z, bias1.w};
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[ks][0], xf[m & 1][ks], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[ks][1], xf[m & 1][ks], acc, 0, 0, 0);
+                }
+                // the 3x3's output rows whose t1 row tiles (0 .. m - 1 are stored at this point) are complete
+#pragma unroll
+                for (int r = 0; r < BT_H; ++r)
+                    if (r >= next_row && (18 * r + 53) / 16 + 1 <= m) conv2_row(r);
+#pragma unroll
+                for (int r = 0; r < BT_H; ++r)
+                    if (r >= next_row && (18 * r + 53) / 16 + 1 <= m) next_row = r + 1;
+                store_t1(m, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < BT_H; ++r)
+                if (r >= next_row) conv2_row(r);
         }
-        stamp(1);
+        stamp(0);
         if constexpr (!T1LO) {
 #pragma unroll
             for (int r = 0; r < BT_H; ++r) *reinterpret_cast<uint2*>(A + L::T2LO_OFF + a_wr + r * 4096) = t2lo[r];
         }
+        // ---- everything conv3 needs from global memory is requested BEFORE the X DMA of the next tile goes out: vmcnt counts in issue
+        // order, a load behind the DMA burst would wait for the burst's HBM round trip at its first use
+        f16x8 w3f[KS3][4];
+#pragma unroll
+        for (int ks = 0; ks < KS3; ++ks)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) w3f[ks][f] = wfrag(w3r, ks * 4 + f);
+        uint4 resh[DS ? 1 : BT_H], resl[XLO ? BT_H : 1];
+        static_assert(!(DS && XLO), "the downsample variant has no identity residual");
+        if constexpr (!DS) {
+            // identity: the block input at the tile's own pixels, in accumulator layout (16 B per lane; L2 / MALL hits: the tile was staged from there)
+#pragma unroll
+            for (int rr = 0; rr < BT_H; ++rr) {
+                const int oy = min(ty * BT_H + rr, p.H - 1), ox = min(tx * BT_W + co, p.W - 1);
+                const unsigned roff = (unsigned)(oy * p.W + ox) * (unsigned)p.in_ld + (unsigned)ch0;
+                resh[rr] = *reinterpret_cast<const uint4*>(p.x + roff);
+                if constexpr (XLO) resl[rr] = *reinterpret_cast<const uint4*>(p.x_lo + roff);
+            }
+        }
+        stamp(1);
         stamp(2);
         __syncthreads();                                   // B2: t2 visible; every wave is done with the X tile it read in conv1
         stamp(3);
@@ -314,15 +318,24 @@ __global__ void __launch_bounds__(512) k_bottleneck(BnArgs p) {
         const __amdgpu_buffer_rsrc_t olrsrc = __builtin_amdgcn_make_buffer_rsrc(OLO ? p.out_lo : p.out, 0, p.out_bytes, 0x00020000);
         {
             const float4 b0 = *reinterpret_cast<const float4*>(p.b3 + ch0), b1 = *reinterpret_cast<const float4*>(p.b3 + ch0 + 4);
-#pragma unroll
-            for (int r = 0; r < BT_H; ++r) {
-                if (!DS && r < 3 && more) stage_group(tile + gridDim.x, lds0, r);       // the next X tile, one third per row: B2 is behind us
-                f32x4 a0 = f32x4{b0.x, b0.y, b0.z, b0.w}, a1 = f32x4{b1.x, b1.y, b1.z, b1.w};
+            auto read_t2 = [&](int r, f16x8 (&tf)[8]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const unsigned base = t2_rd ^ (unsigned)(ks << 6);
-                    const f16x8 th = *reinterpret_cast<const f16x8*>(A + base + r * 4096);
-                    const f16x8 tl = *reinterpret_cast<const f16x8*>(A + L::T2LO_OFF + base + r * 4096);
+                    tf[2 * ks] = *reinterpret_cast<const f16x8*>(A + base + r * 4096);
+                    tf[2 * ks + 1] = *reinterpret_cast<const f16x8*>(A + L::T2LO_OFF + base + r * 4096);
+                }
+            };
+            f16x8 tf[2][8];
+            read_t2(0, tf[0]);
+#pragma unroll
+            for (int r = 0; r < BT_H; ++r) {
+                if (!DS && r < 3 && more) stage_group(tile + gridDim.x, lds0, r);       // the next X tile, one third per row: B2 is behind us
+                if (r + 1 < BT_H) read_t2(r + 1, tf[(r + 1) & 1]);                        // next row's fragments beside this row's MFMAs
+                f32x4 a0 = f32x4{b0.x, b0.y, b0.z, b0.w}, a1 = f32x4{b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const f16x8 th = tf[r & 1][2 * ks], tl = tf[r & 1][2 * ks + 1];
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3f[ks][0], th, a0, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3f[ks][2], th, a1, 0, 0, 0);
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3f[ks][1], th, a0, 0, 0, 0);
@@ -373,14 +386,10 @@ __global__ void __launch_bounds__(512) k_bottleneck(BnArgs p) {
             }
         }
         stamp(5);
-        if (more) {      // the next tile's first conv1 weights (in front of this tile's stores)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) { w1pre[ks][0] = w1g[ks * 128]; w1pre[ks][1] = w1g[ks * 128 + 64]; }
-        }
         // the next X tile has landed: behind its last DMA instruction this wave issued the stores of rows 2 .. 7 (all 8 rows where the DMA went
-        // out at the top of the tile) and the four weight loads above -- at least; anything hipcc adds only makes the wait stricter
+        // out at the top of the tile) -- at least; anything hipcc adds only makes the wait stricter
         {
-            constexpr int NTAIL = (DS ? BT_H : BT_H - 2) * (OLO ? 2 : 1) + 4;
+            constexpr int NTAIL = (DS ? BT_H : BT_H - 2) * (OLO ? 2 : 1);
             if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NTAIL) : "memory");
         }
         __syncthreads();                                       // B3: ... for every wave; t2 (and, DS, this X tile) is read
@@ -433,7 +442,7 @@ int launch_bn(const BnArgs& a, hipStream_t s) {
         for (int i = 0; i < grid * 8; ++i)
             for (int k = 0; k < 10; ++k) sum[k] += (double)dbg[i * 10 + k];
         const double n = sum[9] > 0 ? sum[9] : 1;
-        fprintf(stderr, "[bottleneck probe] cin %d ds %d t1lo %d xlo %d olo %d, %.1f tiles per wave; cycles per tile: conv1 %.0f | t1 store + conv2 + t2 store %.0f | t2 lo + preloads %.0f | B2 %.0f | DMA issue %.0f | conv3 + pack %.0f | landing + B3 %.0f | stores %.0f | - %.0f | sum %.0f\n",
+        fprintf(stderr, "[bottleneck probe] cin %d ds %d t1lo %d xlo %d olo %d, %.1f tiles per wave; cycles per tile: conv1 + conv2 %.0f | t2 lo + preloads %.0f | - %.0f | B2 %.0f | - %.0f | conv3 + pack + stores %.0f | landing + B3 %.0f | - %.0f | - %.0f | sum %.0f\n",
                 CIN, (int)DS, (int)T1LO, (int)XLO, (int)OLO, n / (grid * 8), sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n, sum[6] / n, sum[7] / n, sum[8] / n,
                 (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6] + sum[7] + sum[8]) / n);
     }
