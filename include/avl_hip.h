@@ -336,6 +336,11 @@ int avl_seg_plan_capture(avl_seg_plan* plan, void* stream);
  * flops_host / bytes_host (either may be NULL) receive each op's algorithmic flops and bytes. */
 int avl_seg_plan_profile(avl_seg_plan* plan, void* stream, float* ms_host, double* flops_host, double* bytes_host);
 int avl_seg_plan_num_ops(const avl_seg_plan* plan);
+/* diagnostic: runs the ops one by one and counts the Inf / NaN values of every op's output planes where they are produced
+ * (counts_host[n_ops]; blocks until done, never inside a capture).  The 16-bit precisions turn an fp32 accumulator beyond the
+ * type's range into Inf in the producing op's epilogue; a later ReLU can hide that from the logits.  SemanticSegmentation's
+ * load-time self-check (semantic_segmentation.py:28-32 loads real checkpoints) refuses a plan with a non-zero count. */
+int avl_seg_plan_nonfinite(avl_seg_plan* plan, void* stream, unsigned long long* counts_host);
 
 #ifdef __cplusplus
 }

@@ -127,3 +127,14 @@ def test_grouped_conv_windows_are_block_diagonal(groups):
         for i in (0, 3, 6, 15):
             co_local = (i >> 2) * 8 + nj * 4 + (i & 3)
             assert torch.equal(frag[1, nj, :, i, :].double(), dense[1, co_local])
+
+
+def test_self_check_switch_is_parsed_strictly():
+    """bool('off') is True -- MODEL.MIXED_SELF_CHECK accepts 'auto', booleans and their usual spellings only"""
+    import pytest
+    from vision_semantic_segmentation_amd.semantic_segmentation import _strict_bool
+    assert _strict_bool(True, "x") is True and _strict_bool("off", "x") is False and _strict_bool("False", "x") is False and _strict_bool("on", "x") is True
+    with pytest.raises(ValueError):
+        _strict_bool("maybe", "x")
+    with pytest.raises(ValueError):
+        _strict_bool(2, "x")

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Where does a 16-bit plan leave the fp32 reference?  Runs growing prefixes of a SegNet plan (ops 0 .. k for every op that ends a
+backbone block, the ASPP and the decoder) and compares the hi (+ f16 lo) planes that op writes with the oracle's tensor at the same place.
+
+    python tools/layer_error_trace.py [--heavy SEED | --seed SEED] [--precision mixed] [--hw 320 416] [--opts k=v,k=v]
+
+prints per stage: max |d| / max |ref| over the tensor, and the worst PER-CHANNEL figure max_c (max |d_c| / max |ref_c|) -- with
+heavy-tailed channel scales a small channel can be wrong by 100 % without showing in the first number."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests")))
+import _full_size as fs  # noqa: E402
+from oracle import network_oracle as no  # noqa: E402
+from vision_semantic_segmentation_amd import _lib  # noqa: E402
+from vision_semantic_segmentation_amd.network import AvlSegOp, SegNet  # noqa: E402
+
+
+def oracle_stages(st, img):
+    out = {}
+    with torch.no_grad():
+        x = no.normalize_image(img)
+        x = F.relu(no._bn(F.conv2d(x, st["backbone.conv1.weight"], stride=2, padding=3), st, "backbone.bn1"))
+        out["backbone.conv1"] = x
+        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        out["backbone.maxpool"] = x
+        low = None
+        for p, stride, dilation in no.layer_plan(st, 8):
+            if p.startswith("backbone.layer2.0") and low is None:
+                low = x
+            x = no.bottleneck(x, st, p, stride, dilation)
+            out[p] = x
+        y = no.aspp_forward(st, x, (1, 12, 24, 36))
+        out["aspp.conv"] = y
+        out["logits"] = no.decoder_forward(st, y, low)
+    return out
+
+
+def tensor_at(net, ptr, rows, cols, ld, dtype):
+    es = torch.tensor([], dtype=dtype).element_size()
+    for t in net._keep + [net.logits_buf]:
+        lo, hi = t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()
+        if lo <= ptr < hi:
+            flat = t.reshape(-1).view(torch.uint8)[ptr - lo:].view(dtype)
+            return torch.as_strided(flat, (rows, cols), (ld, 1)).float().cpu()
+    raise KeyError("pointer %x not in the plan's buffers" % ptr)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--heavy", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--precision", default="mixed")
+    ap.add_argument("--hw", type=int, nargs=2, default=(320, 416))
+    ap.add_argument("--opts", default="")
+    a = ap.parse_args()
+    st = fs.heavy_tailed_state_dict(a.heavy) if a.heavy is not None else fs.state_dict(a.seed)
+    h, w = a.hw
+    img = np.random.default_rng(50 + (a.heavy or 0)).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    ref = oracle_stages(st, img)
+    opts = dict((kv.split("=")[0], bool(int(kv.split("=")[1]))) for kv in a.opts.split(",") if kv)
+    net = SegNet(st, h, w, precision=a.precision, device="cuda:0", **opts)
+    net.image.copy_(torch.from_numpy(img).cuda())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ends = {}
+    for i, n in enumerate(net.op_names):
+        for key in ref:
+            if n == key or n in (key + ".conv3", key + ".conv3+downsample"):
+                ends[key] = i
+        if n.startswith("decoder.refine_layers.") and net.ops[i].out_f32:
+            ends["logits"] = i
+    dt = torch.float32 if a.precision == "f32" else (torch.bfloat16 if a.precision == "bf16" else torch.float16)
+    for key, k in sorted(ends.items(), key=lambda kv: kv[1]):
+        plan = C.c_void_p()
+        arr = (AvlSegOp * (k + 1))(*net.ops[:k + 1])
+        _lib.check(_lib.lib().avl_seg_plan_create(arr, k + 1, C.byref(plan)), "create")
+        _lib.check(_lib.lib().avl_seg_plan_run(plan, s), "run")
+        torch.cuda.synchronize()
+        op = net.ops[k]
+        rows, cols = op.out_h * op.out_w, op.out_c
+        got = tensor_at(net, op.out, rows, cols, op.out_ld, torch.float32 if op.out_f32 else dt)
+        if op.out_lo:
+            got = got + tensor_at(net, op.out_lo, rows, cols, op.out_ld, dt)
+        _lib.lib().avl_seg_plan_destroy(plan)
+        r = ref[key][0].permute(1, 2, 0).reshape(rows, cols)
+        d = (got - r).abs()
+        per_c = (d.amax(dim=0) / r.abs().amax(dim=0).clamp_min(1e-30))
+        wc = int(per_c.argmax())
+        print("%-28s max|d|/max|ref| %.2e   worst channel %4d: %.2e (its max|ref| %.3g, tensor max %.3g)   rms %.2e" % (
+            key, float(d.max() / r.abs().max()), wc, float(per_c[wc]), float(r[:, wc].abs().max()), float(r.abs().max()),
+            float(d.pow(2).mean().sqrt() / r.abs().max())), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -104,9 +104,12 @@ def get_network_cfg_defaults():
     C.MODEL.MIXED_CONV2_SPLIT = True    # "mixed" only: keep every bottleneck's 3x3 output as hi + lo (conv3 corrects for both parts)
     C.MODEL.MIXED_LAYER1_LO = False     # "mixed" only: True = layer1's first two blocks keep a lo plane of their output as well (the last block always does):
                                         # -10..-30 % logits error (worst draw 7.3e-4 instead of 8.2e-4 at 1080p) for +0.4 GB of HBM traffic per frame (-2.5 % frames/s)
-    C.MODEL.MIXED_SELF_CHECK = "auto"   # "mixed" only: compare the first plan against the fp32-input HIP path on one seeded frame and switch MIXED_LAYER1_LO on
-                                        # when the logits differ by more than 8e-4 (SemanticSegmentation.check_mixed_against_f32).  "auto" = when MODEL.WEIGHT
-                                        # names a checkpoint (the margins of DESIGN section 4 were measured on random-init weights); True / False force it
+    C.MODEL.MIXED_SELF_CHECK = "auto"   # "mixed" only: before the first plan, measure a ladder of plans (mixed -> + layer1 lo planes -> all-f16 split ->
+                                        # f32) against the fp32-input HIP path on four seeded frames, scan every 16-bit tensor for Inf / NaN, and keep the
+                                        # first plan within 1e-3 (SemanticSegmentation.check_mixed_against_f32).  "auto" = when MODEL.WEIGHT names a
+                                        # checkpoint (the margins of DESIGN section 4 were measured on seeded weights); True / False force it
+    C.MODEL.MIXED_ON_FAIL = "f32"       # what the self-check does when no 16-bit plan passes: "f32" = run the fp32 plan (4x slower), "raise", or "warn"
+                                        # (keep the best finite 16-bit plan)
     C.MODEL.SEED = 0               # seed of the random weights used when MODEL.WEIGHT == ""
     C.MODEL.HIP_GRAPH = True       # replay the ~90-kernel plan as one hipGraph launch per frame
     return C

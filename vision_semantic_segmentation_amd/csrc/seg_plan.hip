@@ -193,6 +193,64 @@ extern "C" int avl_seg_plan_profile(avl_seg_plan* plan, void* stream, float* ms_
     return AVL_OK;
 }
 
+// ---- avl_seg_plan_nonfinite: the plan op by op, each op's output planes scanned for Inf / NaN where they are produced.
+// The 16-bit modes convert fp32 accumulators to f16 / bf16 in every epilogue: a value beyond the type's range becomes Inf there, and
+// a later ReLU can turn -Inf into a plausible 0 -- so an overflow is looked for at its source, not in the logits.  Diagnostic entry
+// point (SemanticSegmentation's load-time self-check runs it once per checkpoint); never part of a frame.
+namespace avl {
+namespace {
+template <typename T>
+__global__ void k_count_nonfinite(const T* x, long long rows, int cols, int ld, unsigned long long* counter) {
+    const long long n = rows * cols;
+    unsigned long long bad = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = (float)x[(i / cols) * ld + (i % cols)];
+        bad += (__builtin_isfinite(v) ? 0u : 1u);
+    }
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_down(bad, o, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(counter, bad);
+}
+template <typename T>
+void count_plane(const void* ptr, long long rows, int cols, int ld, unsigned long long* counter, hipStream_t s) {
+    if (!ptr || rows <= 0 || cols <= 0) return;
+    hipLaunchKernelGGL((k_count_nonfinite<T>), dim3(512), dim3(256), 0, s, static_cast<const T*>(ptr), rows, cols, ld, counter);
+}
+}  // namespace
+}  // namespace avl
+
+extern "C" int avl_seg_plan_nonfinite(avl_seg_plan* plan, void* stream, unsigned long long* counts_host) {
+    AVL_REQUIRE(plan && counts_host, "avl_seg_plan_nonfinite: bad arguments");
+    hipStream_t s = avl::as_stream(stream);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    AVL_HIP_CHECK(hipStreamIsCapturing(s, &cap));
+    AVL_REQUIRE(cap == hipStreamCaptureStatusNone, "avl_seg_plan_nonfinite synchronises the stream: not while it is being captured");
+    const size_t n = plan->ops.size();
+    unsigned long long* dev = nullptr;
+    AVL_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dev), n * sizeof(unsigned long long)));
+    int rc = AVL_OK;
+    hipError_t e = hipMemsetAsync(dev, 0, n * sizeof(unsigned long long), s);
+    for (size_t i = 0; i < n && rc == AVL_OK && e == hipSuccess; ++i) {
+        const avl_seg_op& op = plan->ops[i];
+        rc = avl::launch(op, s);
+        if (rc) break;
+        if (op.kind == AVL_OP_ARGMAX) continue;                 // uint8 labels
+        const long long rows = (op.kind == AVL_OP_GAP || op.kind == AVL_OP_GEMV) ? 1 : (long long)op.out_h * op.out_w;
+        const bool f32 = op.dtype == AVL_F32 || op.out_f32 || op.kind == AVL_OP_GAP || op.kind == AVL_OP_GEMV;
+        if (f32) avl::count_plane<float>(op.out, rows, op.out_c, op.out_ld, dev + i, s);
+        else if (op.dtype == AVL_F16) {
+            avl::count_plane<avl::f16>(op.out, rows, op.out_c, op.out_ld, dev + i, s);
+            avl::count_plane<avl::f16>(op.out_lo, rows, op.out_c, op.out_ld, dev + i, s);
+        } else avl::count_plane<avl::bf16>(op.out, rows, op.out_c, op.out_ld, dev + i, s);
+        e = hipGetLastError();
+    }
+    if (rc == AVL_OK && e == hipSuccess) e = hipMemcpyAsync(counts_host, dev, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    if (rc == AVL_OK && e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dev);
+    if (rc) return rc;
+    if (e != hipSuccess) return avl::set_error(AVL_E_HIP, "avl_seg_plan_nonfinite: %s", hipGetErrorString(e));
+    return AVL_OK;
+}
+
 namespace avl {
 int launch_preprocess(const unsigned char*, int, int, const double*, const double*, int, unsigned char*, hipStream_t);
 int launch_set_camera(void*, const double*, const double*, hipStream_t);

@@ -59,6 +59,7 @@ _lib._register_seg({
     "avl_seg_plan_capture": (_i, [_vp, _vp]),
     "avl_seg_plan_profile": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "avl_seg_plan_num_ops": (_i, [_vp]),
+    "avl_seg_plan_nonfinite": (_i, [_vp, _vp, _vp]),
 })
 
 # ----------------------------------------------------------------------------------------------
@@ -148,6 +149,10 @@ def check_state_dict(state, **kw):
     missing = [k for k, s in state_spec(**kw) if k not in state or tuple(state[k].shape) != tuple(s)]
     if missing:
         raise KeyError("state dict lacks / mis-shapes %d tensors, e.g. %s" % (len(missing), missing[:3]))
+    # the kernels' ReLU is a max with 0, which turns a NaN into 0 (torch's keeps it): a NaN weight would vanish silently
+    bad = [k for k, _ in state_spec(**kw) if not bool(torch.isfinite(state[k]).all())]
+    if bad:
+        raise ValueError("state dict holds Inf / NaN in %d tensors, e.g. %s" % (len(bad), bad[:3]))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -1002,6 +1007,15 @@ class SegNet(object):
         s = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(_lib.lib().avl_seg_plan_profile(self._plan, C.c_void_p(s), ms, fl, by), "avl_seg_plan_profile")
         return [dict(name=self.op_names[i], kind=OP_NAMES[self.ops[i].kind], ms=ms[i], flops=fl[i], bytes=by[i]) for i in range(n)]
+
+    def nonfinite_counts(self):
+        """Runs the plan's ops one by one (never the captured graph) and counts Inf / NaN values in every op's output where it is
+        produced -> {op name: count} of the ops that produced any.  An f16 overflow shows up here even where a later ReLU hides it."""
+        n = len(self.ops)
+        cnt = (C.c_ulonglong * n)()
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().avl_seg_plan_nonfinite(self._plan, C.c_void_p(s), cnt), "avl_seg_plan_nonfinite")
+        return {self.op_names[i]: int(cnt[i]) for i in range(n) if cnt[i]}
 
     def total_flops(self):
         n = len(self.ops)

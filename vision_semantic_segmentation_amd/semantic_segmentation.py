@@ -17,6 +17,17 @@ from . import _lib
 from .network import SegNet, check_state_dict, load_checkpoint, random_state_dict
 
 
+def _strict_bool(v, what):
+    """True / False, or the strings yacs' merge_from_list may hand over; anything else is an error (bool('off') is True)."""
+    if isinstance(v, bool):
+        return v
+    if isinstance(v, str) and v.strip().lower() in ("true", "on", "1", "yes"):
+        return True
+    if isinstance(v, str) and v.strip().lower() in ("false", "off", "0", "no"):
+        return False
+    raise ValueError("%s must be 'auto', True or False, not %r" % (what, v))
+
+
 class SemanticSegmentation(object):
     def __init__(self, cfg, device=None, state_dict=None):
         """cfg: network configuration (cfg.VISION_SEM_SEG.SEM_SEG_NETWORK of base_cfg.py:96-112)."""
@@ -40,13 +51,24 @@ class SemanticSegmentation(object):
             self.state = random_state_dict(seed=getattr(cfg.MODEL, "SEED", 0), **kw)
         check_state_dict(self.state, **kw)
         self._nets = {}
-        # "mixed" self-check: the logits error of the mixed mode follows the WEIGHTS and was measured
-        # on random draws only, so a real checkpoint is checked once against the fp32-input HIP path (itself 2e-6 from the fp32
-        # reference) on one seeded frame; the speed option MIXED_LAYER1_LO = False is given up when the error passes 8e-4.
+        # "mixed" self-check: the logits error of the mixed mode follows the WEIGHTS and was measured on seeded
+        # draws only, so a real checkpoint is checked once, before its first plan, against the fp32-input HIP path (itself 2e-6 from
+        # the fp32 reference) on several seeded frames, and every 16-bit tensor of the plan is scanned for Inf / NaN where it is
+        # produced.  The check walks a LADDER of plans and keeps the first one that passes:
+        #   "mixed"       as configured (f16 + FP4 matrix cores)
+        #   "mixed+lo"    + MIXED_LAYER1_LO (every layer1 block keeps its lo plane)
+        #   "split16"     every correction product as an f16 pass on f16 hi + lo planes, no FP4 anywhere (round 2's 173 frames/s form)
+        #   "f32"         fp32-input MFMA, the reference's precision (50 frames/s)
         sc = getattr(cfg.MODEL, "MIXED_SELF_CHECK", "auto")
-        self._self_check = (state_dict is None and bool(cfg.MODEL.WEIGHT)) if sc == "auto" else bool(sc)
+        self._self_check = (state_dict is None and bool(cfg.MODEL.WEIGHT)) if sc == "auto" else _strict_bool(sc, "MODEL.MIXED_SELF_CHECK")
         self._layer1_lo = bool(getattr(cfg.MODEL, "MIXED_LAYER1_LO", False))
-        self.mixed_check = None            # {"size", "rel_err", "layer1_lo", ...} once the check has run
+        self._rung = "mixed+lo" if self._layer1_lo else "mixed"     # which plan of the ladder the "mixed" precision currently means
+        self.on_fail = str(getattr(cfg.MODEL, "MIXED_ON_FAIL", "f32"))
+        if self.on_fail not in ("f32", "raise", "warn"):
+            raise ValueError("MODEL.MIXED_ON_FAIL must be 'f32', 'raise' or 'warn', not %r" % self.on_fail)
+        self.mixed_check = None            # {"size", "rel_err", "rung", "tried", ...} once the check has run
+
+    LADDER = ("mixed", "mixed+lo", "split16", "f32")
 
     def net_for(self, h, w, raw_frame=None):
         """The compiled plan for an h x w network input (built on first use, kept per size).  raw_frame = (src_h, src_w): the plan
@@ -55,47 +77,101 @@ class SemanticSegmentation(object):
         if key not in self._nets:
             if self._self_check and self.precision == "mixed" and self.mixed_check is None:
                 self.check_mixed_against_f32(key[0], key[1])
-            net = self._build(key[0], key[1], self.precision, raw_frame, self._layer1_lo)
+            rung = self._rung if self.precision == "mixed" else self.precision
+            if rung == "f32" and raw_frame is not None:
+                raise NotImplementedError("the self-check fell back to the fp32 plan, which has no pre-processing stem: "
+                                          "use preprocess_device() + segmentation_device()")
+            net = self._build(key[0], key[1], rung, raw_frame)
             if getattr(self.cfg.MODEL, "HIP_GRAPH", True):
                 net.capture_graph()
             self._nets[key] = net
         return self._nets[key]
 
-    def _build(self, h, w, precision, raw_frame, layer1_lo):
-        return SegNet(self.state, h, w, precision=precision, device=self.device, num_classes=self.num_classes, raw_frame=raw_frame,
+    def _build(self, h, w, rung, raw_frame=None):
+        """rung: a plan of the ladder ("mixed", "mixed+lo", "split16") or a plain precision ("f32", "f16", "bf16")"""
+        kw = dict(device=self.device, num_classes=self.num_classes, raw_frame=raw_frame)
+        if rung in ("f32", "f16", "bf16"):
+            return SegNet(self.state, h, w, precision=rung, **kw)
+        if rung == "split16":
+            return SegNet(self.state, h, w, precision="mixed", mx=False, gconv_mx=False, trunk_fp4=False, layer1_lo=True, **kw)
+        return SegNet(self.state, h, w, precision="mixed",
                       conv2_split=bool(getattr(self.cfg.MODEL, "MIXED_CONV2_SPLIT", True)),
                       gconv_mx=bool(getattr(self.cfg.MODEL, "MIXED_GCONV_MX", True)),
                       trunk_fp4=bool(getattr(self.cfg.MODEL, "MIXED_TRUNK_FP4", True)),
-                      layer1_lo=layer1_lo)
+                      layer1_lo=(rung == "mixed+lo"), **kw)
+
+    @staticmethod
+    def check_frames(h, w, seed=1, n_noise=3):
+        """The self-check's frames: `n_noise` uniform-noise frames and one smooth frame (low-frequency colour ramps + a few blobs: real
+        camera frames excite far fewer high-frequency channels than noise does)."""
+        rng = np.random.default_rng(seed)
+        frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(n_noise)]
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        smooth = np.stack([128 + 100 * np.sin(2 * np.pi * (xx / w * (1 + k) + yy / h * (2 - k) * 0.5) + k) for k in range(3)], axis=2)
+        for _ in range(6):
+            cy, cx, r = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(0.05, 0.2) * min(h, w)
+            smooth += (rng.uniform(-80, 80, size=3) * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * r * r))[..., None])
+        frames.append(np.clip(smooth, 0, 255).astype(np.uint8))
+        return frames
 
     def check_mixed_against_f32(self, h, w, threshold=8e-4, seed=1):
-        """One seeded h x w frame through the mixed plan and through the fp32-input plan (MODEL.PRECISION = "f32": exact fp32 FMA
-        chains on the matrix cores, 2e-6 from the reference's fp32 forward): max |dlogit| / max |logit|.  If the configured mixed
-        options exceed `threshold` and MIXED_LAYER1_LO is off, the plan with it on is measured as well and the better of the two is what
-        every plan built afterwards uses.
-        Returns (and keeps in .mixed_check) what was measured; warns when even that stays above north_star's 1e-3."""
+        """Several seeded h x w frames (check_frames) through the plans of the ladder and through the fp32-input plan: the WORST
+        max |dlogit| / max |logit| over the frames decides.  A plan FAILS when that figure is not finite, when its logits hold an Inf /
+        NaN, when any of its tensors does (avl_seg_plan_nonfinite: an f16 overflow that a later ReLU would hide), or when the error is
+        above 1e-3; it is ACCEPTED at once when the error is at most `threshold`, otherwise the next rung is measured too and the best
+        passing one is kept.  When no 16-bit plan passes: MODEL.MIXED_ON_FAIL = "f32" (default) uses the fp32 plan from now on,
+        "raise" raises, "warn" keeps the best-effort 16-bit plan with a warning.  A checkpoint whose fp32 logits are not finite raises.
+        Returns (and keeps in .mixed_check) what was measured."""
         import warnings
-        frame = torch.from_numpy(np.random.default_rng(seed).integers(0, 256, size=(h, w, 3), dtype=np.uint8)).to(self.device)
-        ref = self._build(h, w, "f32", None, False)
-        ref.forward(frame)
-        logits_ref = ref.logits.float().clone()
+        frames = [torch.from_numpy(f).to(self.device) for f in self.check_frames(h, w, seed)]
+        ref = self._build(h, w, "f32")
+        refs = []
+        for f in frames:
+            ref.forward(f)
+            refs.append(ref.logits.float().clone())
         del ref
-        scale = float(logits_ref.abs().max())
-        tried = []
-        for lo in ([self._layer1_lo] if self._layer1_lo else [False, True]):
-            net = self._build(h, w, "mixed", None, lo)
-            net.forward(frame)
-            err = float((net.logits.float() - logits_ref).abs().max()) / scale
+        if not all(bool(torch.isfinite(r).all()) for r in refs):
+            raise RuntimeError("the checkpoint's logits are not finite even in fp32: %s" % (self.cfg.MODEL.WEIGHT or "<state_dict>"))
+        tried, best = [], None
+        start = self.LADDER.index(self._rung)
+        for rung in self.LADDER[start:-1]:
+            net = self._build(h, w, rung)
+            err, finite = 0.0, True
+            for f, r in zip(frames, refs):
+                net.forward(f)
+                lg = net.logits.float()
+                finite = finite and bool(torch.isfinite(lg).all())
+                e = float((lg - r).abs().max()) / float(r.abs().max())
+                err = e if not (e <= err) else err          # NaN-safe maximum: a NaN error sticks
+            bad = net.nonfinite_counts() if finite else {"logits": 1}
             del net
-            tried.append((lo, err))
-            if err <= threshold:
+            ok = finite and not bad and (err <= 1e-3)
+            tried.append({"rung": rung, "rel_err": err, "finite": finite, "nonfinite_ops": sorted(bad)[:4], "passes": ok})
+            if ok and (best is None or err < best[1]):
+                best = (rung, err)
+            if ok and err <= threshold:
                 break
         torch.cuda.empty_cache()
-        self._layer1_lo, err = min(tried, key=lambda t: t[1])      # (the maximum over 2.4 M logits is noisy: the lo planes lower it on most draws, not on all)
-        self.mixed_check = {"size": (h, w), "threshold": threshold, "tried": tried, "layer1_lo": self._layer1_lo, "rel_err": err}
-        if err > 1e-3:
-            warnings.warn("mixed precision: logits differ from the fp32 path by %.2e of max|logit| with these weights (> 1e-3); "
-                          "use MODEL.PRECISION = 'f32' if the 1e-3 bound matters more than speed" % err)
+        self.mixed_check = {"size": (h, w), "threshold": threshold, "frames": len(frames), "tried": tried}
+        if best is not None:
+            self._rung, err = best
+        else:
+            summary = "; ".join("%s: %s" % (t["rung"], ("%.2e" % t["rel_err"]) if t["finite"] and not t["nonfinite_ops"]
+                                            else "Inf/NaN in " + ", ".join(t["nonfinite_ops"])) for t in tried)
+            msg = ("mixed precision: no 16-bit plan reproduces the fp32 logits of these weights within 1e-3 on %d frames (%s)"
+                   % (len(frames), summary))
+            if self.on_fail == "raise":
+                raise RuntimeError(msg)
+            usable = [t for t in tried if t["finite"] and not t["nonfinite_ops"]]
+            if self.on_fail == "warn" and usable:
+                t = min(usable, key=lambda t: t["rel_err"])
+                self._rung, err = t["rung"], t["rel_err"]
+                warnings.warn(msg + "; keeping '%s' (MODEL.MIXED_ON_FAIL = 'warn')" % self._rung)
+            else:
+                self._rung, err = "f32", 0.0
+                warnings.warn(msg + "; using the fp32 plan (4x slower)")
+        self._layer1_lo = self._rung != "mixed"
+        self.mixed_check.update(rung=self._rung, layer1_lo=self._layer1_lo, rel_err=err)
         return self.mixed_check
 
     def segmentation_device(self, image_in):
