@@ -76,12 +76,18 @@ def test_no_kernel_of_the_built_library_spills_or_owns_scratch():
     kn = _notes()
     notes = kn.kernel_notes(SO)
     assert len(notes) > 50
-    for family in ("k_gemm_mx_pipe", "k_gemm_ring_mx", "k_gemm_ring", "k_gconv_mfma", "k_dwpw", "k_dwpw_x", "k_stem_mfma", "k_fused_vote"):
+    for family in ("k_gemm_mx_pipe", "k_gemm_ring_mx", "k_gemm_ring", "k_gconv_mfma", "k_dwpw", "k_dwpw_x", "k_stem_mfma", "k_fused_vote", "k_bottleneck"):
         assert any(family in n for n in notes), "no %s kernel in the built library" % family
     dirty = {n: v for n, v in notes.items() if v["vgpr_spill_count"] or v["private_segment_fixed_size"]}
     assert not dirty, "kernels with VGPR spills / scratch in libavl_hip.so: %s" % dirty
     for n, v in notes.items():
         assert v["vgpr_count"] + 0 <= 512 and v["agpr_count"] <= 256
+        # SGPR spills are v_readlane / v_writelane inside the instruction stream: 99 .. 121 in the shipped MX pipe kernels,
+        # none in the fused bottleneck; a jump past these bounds is a scheduling regression worth a look
+        if "k_gemm_mx_pipe" in n:
+            assert v["sgpr_spill_count"] <= 130, (n, v["sgpr_spill_count"])
+        if "k_bottleneck" in n:
+            assert v["sgpr_spill_count"] == 0, (n, v["sgpr_spill_count"])
 
 
 def test_mx_pipe_stream_holds_no_scalar_loads_and_no_scratch():
@@ -112,12 +118,14 @@ def test_release_library_reads_no_environment_and_holds_no_experiment_kernels():
     assert "getenv" not in undefined
     strings = subprocess.run(["strings", SO], capture_output=True, text=True, check=True).stdout
     for name in ("AVL_MX_PROBE", "AVL_GEMM_PROBE", "AVL_SWEEP_EXP", "AVL_GC_PROBE", "AVL_MX_PIPE", "AVL_MX_LATE", "AVL_MX_TILE",
-                 "AVL_MX_STAGGER", "AVL_APPLY_MODE", "AVL_MASK_MODE", "AVL_GCONV_TH", "AVL_GC_DEPHASE", "AVL_DW_NCHUNK", "AVL_GEMM_DEEP"):
+                 "AVL_MX_STAGGER", "AVL_APPLY_MODE", "AVL_MASK_MODE", "AVL_GCONV_TH", "AVL_GC_DEPHASE", "AVL_DW_NCHUNK", "AVL_GEMM_DEEP",
+                 "AVL_MX_SPREAD", "AVL_MX_PP", "AVL_MX_GRID", "AVL_SWEEP_VEC", "AVL_MX_SAMETILE", "AVL_BN_PROBE"):
         assert name not in strings, name
     names = list(kn.kernel_notes(SO))
     assert not any("k_gemm_w4" in n for n in names)
+    assert not any("k_gemm_mx_pp" in n for n in names)
     import re as _re
-    for n in names:
-        m = _re.search(r"k_gemm_mx_pipe<(\d+), (\d+), (\d+), (\d+)>", n)
-        if m:
-            assert m.group(4) == "0", "probe instantiation in the release library: %s" % n
+    pipe = [_re.search(r"k_gemm_mx_pipe<(\d+), (\d+), (\d+), (\d+), (\d+)>", n) for n in names if "k_gemm_mx_pipe<" in n]
+    assert len(pipe) >= 4 and all(pipe), "k_gemm_mx_pipe's template list changed: update this test (%s)" % [n for n in names if "k_gemm_mx_pipe<" in n][:2]
+    for m in pipe:          # <IO, MI, LATE, PROBE, SPREAD>
+        assert m.group(4) == "0" and m.group(5) == "0", "probe / experiment-schedule instantiation in the release library: %s" % m.group(0)

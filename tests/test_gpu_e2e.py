@@ -182,7 +182,11 @@ def _two_rank_worker(rank, world, port, q):
     sys.path.insert(0, os.path.dirname(__file__))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    except Exception as e:            # (port in use, ...): the parent must not wait for a result that never comes
+        q.put(("error", "rank %d: init_process_group: %r" % (rank, e)))
+        raise
     try:
         from test_distributed_cpu import _frames
         from test_gpu_mapping import _Cam, make_sm
@@ -200,8 +204,11 @@ def _two_rank_worker(rank, world, port, q):
         total32 = sm.global_map(exchange_dtype=torch.float32)
         assert total.is_cuda and torch.equal(sm.map_dev, private)
         if rank == 0:
-            q.put((private.cpu().numpy(), total.cpu().numpy(), total32.cpu().numpy()))
+            q.put(("ok", (private.cpu().numpy(), total.cpu().numpy(), total32.cpu().numpy())))
         dist.barrier()
+    except Exception as e:
+        q.put(("error", "rank %d: %r" % (rank, e)))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -216,12 +223,25 @@ def test_two_ranks_hip_grids_through_a_collective(cuda_device):
     from oracle import mapping_oracle as mo
     from test_distributed_cpu import _cfg, _frames
     from vision_semantic_segmentation_amd import synthetic as syn
+    import queue
+    import socket
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, 29633, q)) for r in range(2)]
+    q = ctx.Queue()
+    with socket.socket() as sock:            # a free port (a fixed one may be taken)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    private0, total, total32 = q.get()
+    try:
+        status, payload = q.get(timeout=180)        # a worker that dies puts ("error", ...) first; one that hangs runs into the timeout
+    except queue.Empty:
+        status, payload = "error", "no result from rank 0 within 180 s (exit codes %r)" % [p.exitcode for p in procs]
+    if status != "ok":
+        for p in procs:
+            p.terminate()
+        pytest.fail(payload)
+    private0, total, total32 = payload
     for p in procs:
         p.join(120)
         assert p.exitcode == 0

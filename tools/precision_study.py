@@ -172,6 +172,10 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     st = N.random_state_dict(seed=int(os.environ.get("PS_SEED", "0")))
+    if os.environ.get("PS_HEAVY"):          # a checkpoint-like draw with calibrated BatchNorm statistics (tests/_full_size.heavy_tailed_state_dict)
+        sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+        import _full_size as fs
+        st = fs.heavy_tailed_state_dict(int(os.environ.get("PS_SEED", "0")))
     img = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8).numpy()
     ref = NO.forward_logits(st, img)
     den = ref.abs().max().item()
@@ -314,6 +318,24 @@ def main():
         report("  + aspp dw all exact", Policy("f16", **e3))
         report("  + aspp dw all exact + stem w split + stem out exact", Policy("f16", **dict(e3, **{"stem:w": X, "stem:a": "f32"})))
         report("  + aspp dw out split only (weights f16)", Policy("f16", **dict(d, **{"aspp.b1.dw:a": "f32", "aspp.b2.dw:a": "f32", "aspp.b3.dw:a": "f32"})))
+    if sel == "heavy":
+        # round 5: which roundings does a CALIBRATED network (every BN subtracts the mean of what it normalises) not forgive?
+        def blocks(which, conv, dd, kind="f32"):
+            for li, b in which:
+                dd["layer%d.%d.%s:a" % (li, b, conv)] = kind
+            return dd
+        ALL = [(li, b) for li, nb in ((1, 3), (2, 4), (3, 6), (4, 3)) for b in range(nb)]
+        report("everything f16 x2 (weights, every tensor)", Policy(X))
+        report("  ... but the stem's output one f16 plane", Policy(X, **{"stem:a": "f16"}))
+        report("  ... but the stem all f16 (weights too)", Policy(X, **{"stem": "f16"}))
+        report("  ... but conv1 outputs one f16 plane", Policy(X, **blocks(ALL, "conv1", {}, "f16")))
+        report("  ... but conv2 outputs one f16 plane", Policy(X, **blocks(ALL, "conv2", {}, "f16")))
+        report("  ... but the trunk f16 + FP4(lo)", Policy(X, **{":t": "f16q4"}))
+        report("  ... but the trunk one f16 plane", Policy(X, **{":t": "f16"}))
+        report("  ... but aspp depthwise stage f16", Policy(X, **{"aspp.b1.dw": "f16", "aspp.b2.dw": "f16", "aspp.b3.dw": "f16"}))
+        report("  ... but the decoder's tensors one f16 plane", Policy(X, **{"dec:a": "f16"}))
+        report("  ... but weights one f16 plane", Policy(X, **{":w": "f16"}))
+        report("  ... stem f16 + conv1 outputs f16 (today's split16)", Policy(X, **blocks(ALL, "conv1", {"stem": "f16"}, "f16")))
     if sel == "r3s":
         def blocks(which, conv, dd):
             for li, b in which:

@@ -1107,11 +1107,7 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
     };
     if (pt < total) set_tile();
     static_assert(NW == 8, "the DMA stagger assumes waves w and w + 4 on one SIMD");
-#ifdef SPREAD_NOSTAGGER
-    const bool early = true;
-#else
     const bool early = wave >= 4 || q.stagger == 0;             // issues its bursts right behind the events; the others LATE steps later
-#endif
     if (pt < total) { issue_w(); issue_a(); }                    // sub-step 0 -> slots 0
     if (pt < total) { issue_w(); issue_a(); }                    // sub-step 1 -> slots 1
 
@@ -1367,317 +1363,7 @@ __global__ void __launch_bounds__(512) k_gemm_mx_pipe(MxArgs q, int mtiles) {
 }
 
 #ifdef AVL_EXPERIMENTS
-// ---------------------------------------------------------------------------------------------
-// k_gemm_mx_pp -- EXPERIMENT (round 4, experiments build only; measured and not adopted: profiles/r04/gemm_mx_pingpong_experiment.log):
-// the MX GEMM as a PING-PONG of the two waves of every SIMD (256 x 256 tiles).
-//
-// Same arithmetic, data layouts, LDS image and epilogue as k_gemm_mx_pipe; what changes is who does what when.  The eight waves form
-// two groups (waves 0-3 = pixel rows 0-127 of the tile, waves 4-7 = rows 128-255: one wave of each group on every SIMD).  A sub-step
-// (64 f16 / 256 FP4 K-values) is cut into four QUADRANTS of a wave's 128 x 64 output (64 pixels x 32 channels: 16 MFMAs), and every
-// quadrant is two phases separated by workgroup barriers:
-//     mem(q):      the quadrant's fragments LDS -> registers (ds_read_b128), two LDS-DMA instructions of the NEXT sub-step's tiles,
-//                  s_waitcnt lgkmcnt(0)
-//     compute(q):  16 MFMAs back to back, nothing else
-// Group 1 runs ONE BARRIER behind group 0 (it passes one extra barrier before its first phase, group 0 one extra at the very end), so
-// in every interval between two barriers one wave of each SIMD issues MFMAs at the full rate of the matrix pipe while its partner
-// reads fragments and pays the issue stalls of its DMA instructions -- the two never compete for the pipe, and a DMA stall never
-// delays the stalled wave's own MFMAs (in k_gemm_mx_pipe each wave interleaves all three).
-//
-// Interval numbering for sub-step g:  group 0: mem(q) = 8 g + 2 q - 1, compute(q) = 8 g + 2 q;  group 1: one later.
-// Fragment reads per wave and sub-step: mem(0): activations of pixel half 0 (8 reads) + weights of n-tiles 0, 1 (4) [+ scales];
-// mem(1): weights of n-tiles 2, 3 (4); mem(2): activations of pixel half 1 (8); mem(3): none.  Quadrant order (i0 j0) (i0 j1) (i1 j1) (i1 j0).
-// LDS-DMA (one cursor: the tiles of sub-step g + 1 are sent during sub-step g, into the other slot): mem(0) / mem(1) send the
-// WEIGHT tile (quarter 2 q + group), mem(2) / mem(3) the group's OWN activation rows (quarter 2 group + q - 2; an FP4 sub-step's
-// scale blocks go with mem(2) of group 1).  Hazards (every mem phase ends with lgkmcnt(0) in front of its barrier, so a read is
-// retired by the barrier that closes its interval):
-//   WAR  weight slot of g + 1 was last read in interval 8 g - 2 (group 1, n-tiles 2 / 3 of sub-step g - 1) -> first written in 8 g - 1;
-//        activation rows of group h in the slot of g + 1 were last read in 8 g - 5 + h -> written from 8 g + 3 on.
-//   RAW  a wave waits `vmcnt(2)` at the end of mem(3) -- everything but the two activation pieces it has just sent -- in front of the
-//        barrier closing 8 g + 5 (group 0) / 8 g + 6 (group 1); the first read of sub-step g + 1 is in 8 g + 7: weights, scales and
-//        the pixel-half-0 rows (sent in mem(2)) are certified.  The pixel-half-1 rows (mem(3)) are read in mem(2) of sub-step g + 1:
-//        they are certified by `vmcnt(4)` at the end of its mem(1) (everything but the four weight pieces sent in mem(0) / mem(1)).
-//        Epilogue loads / stores are older than any piece sent after them: the counts only wait for more.
-template <int IO>
-__global__ void __launch_bounds__(512) k_gemm_mx_pp(MxArgs q, int mtiles) {
-    typedef f16 H;
-    typedef typename Half16<H>::v8 v8;
-    typedef int v8i __attribute__((ext_vector_type(8)));
-    constexpr int MI = 8, BM = 256, BN = 256;
-    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
-    constexpr int W_REGION = 2 * A_BYTES, S_REGION = W_REGION + 2 * W_BYTES, S_BYTES = 4096;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const GemmArgs& p = q.g;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;                    // wm = the wave's group
-    const int nwg = gridDim.x;
-    int vb;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3, qq = nwg >> 3, r = nwg & 7;
-        vb = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + local;
-    }
-    const int ntiles = p.ntiles, nmx = q.nmx;
-    const int total = mtiles * ntiles;
-    const int nmb = p.K / 256;
-    const int nsub = 4 + nmx;
-    const unsigned lds_base = lds_addr(lds);
-
-    // ---- producer (one cursor, as in k_gemm_mx_pipe: scalars re-derived from the argument struct only at a tile switch / input switch)
-    auto lane_now = [&]() __attribute__((always_inline)) {
-        unsigned l;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-        return l;
-    };
-    int pt = vb, pmb = 0, pj = 0, issued = 0, pmbl = 0;
-    long long cur_rowb16 = 0, cur_rowbq = 0, cur_asrows = 0;
-    const char *cur_a16 = nullptr, *cur_aq = nullptr, *cur_as = nullptr, *cur_w16 = nullptr, *cur_wq = nullptr, *cur_ws = nullptr;
-    long long cur_aps = 0, cur_wps = 0;
-    int p_mt = 0;
-    auto set_input = [&](bool second) __attribute__((always_inline)) {
-        const long long rows0 = (long long)p_mt * BM;
-        if (!second) {
-            cur_rowb16 = (long long)p.lda * 2; cur_rowbq = q.ldaq; cur_asrows = q.a_srows;
-            cur_a16 = static_cast<const char*>(p.A) + rows0 * cur_rowb16;
-            cur_aq = q.Aq[0] + rows0 * cur_rowbq;
-            cur_as = q.As[0] + rows0 * 8;
-            cur_aps = q.Aq[1] - q.Aq[0];
-        } else {
-            cur_rowb16 = (long long)q.lda2 * 2; cur_rowbq = q.ldaq2; cur_asrows = q.a_srows2;
-            cur_a16 = static_cast<const char*>(q.A2) + rows0 * cur_rowb16;
-            cur_aq = q.Aq2[0] + rows0 * cur_rowbq;
-            cur_as = q.As2[0] + rows0 * 8;
-            cur_aps = q.Aq2[1] - q.Aq2[0];
-        }
-        pmbl = 0;
-    };
-    auto set_tile = [&]() __attribute__((always_inline)) {
-        const int nt_ = pt % ntiles;
-        p_mt = pt / ntiles;
-        cur_w16 = static_cast<const char*>(p.W) + (long long)nt_ * BN * p.K * 2;
-        cur_wq = q.Wq[0] + (long long)nt_ * BN * (p.K / 2);
-        cur_ws = q.Ws[0] + (long long)nt_ * BN * 8;
-        cur_wps = q.Wq[1] - q.Wq[0];
-        set_input(false);
-    };
-    // One PIECE = a quarter tile (64 rows x 128 B): the group's four waves send two 1 KB instructions each; wave wl, instruction t
-    // covers rows (c * 8 + wl * 2 + t) * 8 + srow.  Weight rows: the swizzle key ((r >> 1) & 1) | (((r >> 4) & 3) << 1) =
-    // ((srow >> 1) & 1) | ((wl & 3) << 1) depends on neither t nor c; activation rows: key = r & 7 = srow.
-    auto send_w = [&](int c) __attribute__((always_inline)) {
-        const unsigned dst = lds_base + W_REGION + (issued & 1) * W_BYTES + (c * 8 + wn * 2) * 1024;
-        const unsigned l = lane_now(), srow = l >> 3, cw = ((l & 7u) ^ (((srow >> 1) & 1u) | ((unsigned)wn << 1))) << 4;
-        const long long row0 = c * 64 + wn * 16;
-        if (pj < 4) {
-            const long long pitch = (long long)p.K * 2;
-            const char* sw = cur_w16 + (long long)(pmb * 4 + pj) * 128 + row0 * pitch;
-            const unsigned wl = srow * (unsigned)pitch + cw;
-            glds16_saddr(sw, wl, dst);
-            glds16_saddr(sw + 8 * pitch, wl, dst + 1024);
-        } else {
-            const long long pitch = p.K / 2;
-            const char* sw = cur_wq + (pj == 4 ? 0 : cur_wps) + (long long)pmb * 128 + row0 * pitch;
-            const unsigned wl = srow * (unsigned)pitch + cw;
-            glds16_saddr(sw, wl, dst);
-            glds16_saddr(sw + 8 * pitch, wl, dst + 1024);
-        }
-    };
-    auto send_a = [&](int c, bool with_scales) __attribute__((always_inline)) {
-        const unsigned dst = lds_base + (issued & 1) * A_BYTES + (c * 8 + wn * 2) * 1024;
-        const unsigned l = lane_now(), srow = l >> 3, ct = ((l & 7u) ^ srow) << 4;
-        const long long row0 = c * 64 + wn * 16;
-        if (pj < 4) {
-            const char* sa = cur_a16 + (long long)(pmbl * 4 + pj) * 128 + row0 * cur_rowb16;
-            const unsigned al = srow * (unsigned)cur_rowb16 + ct;
-            glds16_saddr(sa, al, dst);
-            glds16_saddr(sa + 8 * cur_rowb16, al, dst + 1024);
-        } else {
-            const long long ta = pj == 4 ? 0 : cur_aps, tw = pj == 4 ? 0 : cur_wps;
-            const char* sa = cur_aq + ta + (long long)pmbl * 128 + row0 * cur_rowbq;
-            const unsigned al = srow * (unsigned)cur_rowbq + ct;
-            glds16_saddr(sa, al, dst);
-            glds16_saddr(sa + 8 * cur_rowbq, al, dst + 1024);
-            if (with_scales) {     // 2 KB activation-row scales (waves wn 0, 1), 2 KB weight-row scales (wn 2, 3): one KB per wave
-                const char* ss = wn < 2 ? cur_as + ta + (long long)pmbl * cur_asrows * 8 + wn * 1024
-                                        : cur_ws + tw + (long long)pmb * q.w_srows * 8 + (wn - 2) * 1024;
-                glds16_saddr(ss, l * 16u, lds_base + S_REGION + (issued & 1) * S_BYTES + wn * 1024);
-            }
-        }
-    };
-    auto advance = [&]() __attribute__((always_inline)) {      // the cursor moves on to the next sub-step (after a wave's last piece)
-        ++issued;
-        if (++pj == nsub) {
-            pj = 0;
-            ++pmbl;
-            if (++pmb == nmb) {
-                pmb = 0;
-                pt += nwg;
-                if (pt < total) set_tile();
-            } else if (pmb == q.nmb1) set_input(true);
-        }
-    };
-    if (pt < total) set_tile();
-    // prologue: sub-step 0 whole (both groups: each its own activation rows, the weight quarters 2 q + group)
-    if (pt < total) {
-        send_w(wm); send_w(2 + wm); send_a(2 * wm, false); send_a(2 * wm + 1, false);
-        advance();
-    }
-
-    // ---- consumer addressing (k_gemm_mx_pipe's: one base register per operand, immediates and one XOR for the rest)
-    const int fr = lane & 15, kq = lane >> 4;
-    const int a_row0 = wm * (MI * 16) + fr;
-    const int wrow0 = wn * 64 + (fr >> 2) * 16 + (fr & 3);
-    const int wkey_r = ((wrow0 >> 1) & 1) | (((wrow0 >> 4) & 3) << 1);
-    const unsigned a_v0 = (unsigned)(a_row0 * 128 + ((kq ^ (a_row0 & 7)) << 4));
-    const unsigned w_v0 = (unsigned)(W_REGION + wrow0 * 128 + ((kq ^ wkey_r) << 4));
-    const unsigned sa_v = (unsigned)(S_REGION + a_row0 * 8 + kq);
-    const unsigned sw_v = (unsigned)(S_REGION + 2048 + (wn * 4 + (fr >> 2)) * 128 + ((fr & 3) * 4 + kq) * 8);
-
-    f32x4 acc[MI][4];
-    auto init_acc = [&](int t) {
-        const int nb = (t % ntiles) * BN + wn * 64 + kq * 16;
-#pragma unroll
-        for (int nj = 0; nj < 4; ++nj) {
-            const float4 b = *reinterpret_cast<const float4*>(p.bias + nb + 4 * nj);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) acc[mi][nj] = f32x4{b.x, b.y, b.z, b.w};
-        }
-    };
-    if (vb < total) init_acc(vb);
-
-    int4 Af[2][4], Wf[2][4];                                    // [K half][pixel block of the quadrant] / [K half][n-tile]
-    unsigned As[2][4];
-    uint2 Wsc = make_uint2(0u, 0u);
-    auto rdA = [&](const char* slot, int kk, int mi) { return *reinterpret_cast<const int4*>(slot + (a_v0 ^ (unsigned)(kk * 64)) + mi * 2048); };
-    auto rdW = [&](const char* slot, int kk, int nj) { return *reinterpret_cast<const int4*>(slot + (w_v0 ^ (unsigned)(kk * 64)) + nj * 512); };
-    auto rdAs = [&](const char* slot, int kk, int mi) { return (unsigned)*reinterpret_cast<const unsigned char*>(slot + sa_v + mi * 128 + kk * 4); };
-    auto rdWs = [&](const char* slot) { return *reinterpret_cast<const uint2*>(slot + sw_v); };
-
-    int g = 0;
-    // one quadrant: mem phase, barrier, 16 MFMAs, barrier.  `last`: the tile's last quadrant (the epilogue follows; see below)
-    auto quadrant = [&](auto kind_c, auto q_c) __attribute__((always_inline)) {
-        constexpr int KIND = decltype(kind_c)::value, Q = decltype(q_c)::value;
-        constexpr int I = Q >> 1, J = (Q == 1 || Q == 2) ? 1 : 0;      // (i0 j0) (i0 j1) (i1 j1) (i1 j0)
-        const char* ab = lds + (g & 1) * A_BYTES;
-        const char* wb = lds + (g & 1) * W_BYTES;
-        const char* sb = lds + (g & 1) * S_BYTES;
-        // ---- mem phase
-        if constexpr (Q == 0 || Q == 2) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    Af[kk][m] = rdA(ab, kk, 4 * I + m);
-                    if (KIND == 1) As[kk][m] = rdAs(sb, kk, 4 * I + m);
-                }
-        }
-        if constexpr (Q == 0 || Q == 1) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) Wf[kk][2 * Q + n] = rdW(wb, kk, 2 * Q + n);
-            if (KIND == 1 && Q == 0) Wsc = rdWs(sb);
-        }
-        bool sent = false;
-        if (pt < total) {
-            if constexpr (Q < 2) send_w(2 * Q + wm);
-            else send_a(2 * wm + (Q - 2), Q == 2 && wm == 1);
-            if constexpr (Q == 3) advance();
-            sent = true;
-        }
-        if constexpr (Q == 3) {
-            // everything but the two activation pieces just sent has landed (this wave's share); nothing may stay in flight
-            // once the work has run out
-            if (sent) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        } else if constexpr (Q == 1) {
-            // the pixel-half-1 rows of THIS sub-step were the last pieces of the previous sub-step's mem(3): they are read in mem(2),
-            // two intervals from here -- everything but the four weight pieces sent since (mem(0), mem(1)) has landed
-            if (sent) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- compute phase
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                constexpr int dummy = 0; (void)dummy;
-                const int mi = 4 * I + m;
-                if (KIND == 0) {
-                    const v8 af = __builtin_bit_cast(v8, Af[kk][m]);
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        const int nj = 2 * J + n;
-                        acc[mi][nj] = Half16<H>::mfma(__builtin_bit_cast(v8, Wf[kk][nj]), af, acc[mi][nj]);
-                    }
-                } else {
-                    const v8i xa = {Af[kk][m].x, Af[kk][m].y, Af[kk][m].z, Af[kk][m].w, 0, 0, 0, 0};
-                    const int as = (int)As[kk][m];
-                    const int ws = (int)(J == 0 ? Wsc.x : Wsc.y);
-                    {
-                        const int nj = 2 * J;
-                        const v8i wa = {Wf[kk][nj].x, Wf[kk][nj].y, Wf[kk][nj].z, Wf[kk][nj].w, 0, 0, 0, 0};
-                        acc[mi][nj] = kk == 0 ? __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, acc[mi][nj], 4, 4, 0, ws, 0, as)
-                                              : __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, acc[mi][nj], 4, 4, 1, ws, 0, as);
-                    }
-                    {
-                        const int nj = 2 * J + 1;
-                        const v8i wa = {Wf[kk][nj].x, Wf[kk][nj].y, Wf[kk][nj].z, Wf[kk][nj].w, 0, 0, 0, 0};
-                        acc[mi][nj] = kk == 0 ? __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, acc[mi][nj], 4, 4, 2, ws, 0, as)
-                                              : __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, acc[mi][nj], 4, 4, 3, ws, 0, as);
-                    }
-                }
-            }
-        __builtin_amdgcn_s_setprio(0);
-        // (an empty volatile asm that "touches" the quadrant's accumulators: hipcc otherwise sinks MFMAs below later branches)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) asm volatile("" : "+v"(acc[4 * I + m][2 * J + n]));
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto close = [&]() __attribute__((always_inline)) {        // the barrier that ends a compute phase
-        asm volatile("s_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    typedef std::integral_constant<int, 0> F16;
-    typedef std::integral_constant<int, 1> FP4;
-    typedef std::integral_constant<int, 0> Q0;
-    typedef std::integral_constant<int, 1> Q1;
-    typedef std::integral_constant<int, 2> Q2;
-    typedef std::integral_constant<int, 3> Q3;
-
-    // prologue: sub-step 0 has landed (this wave's share, then everyone's); group 1 falls one barrier behind
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (wm == 1) asm volatile("s_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    for (int t = vb; t < total; t += nwg) {
-        const int nt = t % ntiles, mt = t / ntiles;
-        for (int mb = 0; mb < nmb; ++mb) {
-            const bool last_mb = mb + 1 == nmb;
-            for (int j = 0; j < 4; ++j) {
-                quadrant(F16(), Q0()); close(); quadrant(F16(), Q1()); close(); quadrant(F16(), Q2()); close(); quadrant(F16(), Q3()); close();
-                ++g;
-            }
-            for (int u = 0; u < nmx; ++u) {
-                quadrant(FP4(), Q0()); close(); quadrant(FP4(), Q1()); close(); quadrant(FP4(), Q2()); close(); quadrant(FP4(), Q3());
-                // the tile's last compute phase: group 0 closes it and runs its epilogue in the next interval, group 1 runs its
-                // epilogue INSIDE this interval (it is the one that started a barrier later) and closes afterwards -- both
-                // epilogues run side by side, the barrier sequence of the two groups stays the same
-                if (!(last_mb && u + 1 == nmx)) close();
-                ++g;
-            }
-        }
-        if (wm == 0) close();
-        mx_epilogue<IO, MI>(q, acc, nt, mt, wm, wn, fr, kq);
-        if (t + nwg < total) init_acc(t + nwg);
-        if (wm == 1) close();
-    }
-    if (wm == 0) asm volatile("s_barrier" ::: "memory");        // group 0's share of group 1's last barrier
-}
+#include "experiments/seg_gemm_mx_pp.inc"      // k_gemm_mx_pp (ping-pong schedule experiment): not part of the release translation unit
 #endif  // AVL_EXPERIMENTS
 
 template <int IO, int MI>

@@ -282,7 +282,10 @@ class SemanticMapping(object):
         pinned staging buffer, asynchronously on `stream`) and avl_unpack_pointcloud2 writes float32 [N,4] (x,y,z,intensity)
         straight into the layout the fused frame reads.  Returns (points CUDA float32 [N,4], n_valid CUDA int32 [1]) --
         n_valid is what read_points(skip_nans=True) would have yielded; points that it would have skipped keep their slot
-        with x = NaN and are rejected by the projection kernel."""
+        with x = NaN and are rejected by the projection kernel.
+        With an explicit `stream` the upload and the kernel overlap whatever the current stream is doing (they wait for it only when the
+        staging buffer has just been (re)allocated).  The returned tensors then belong to THAT stream: a caller that consumes them on
+        another stream must make it wait for `stream` first and call ``tensor.record_stream(consumer_stream)`` before dropping them."""
         offs = {f.name: f.offset for f in msg.fields}
         n = int(msg.width) * int(msg.height)
         step = int(msg.point_step)
@@ -293,8 +296,6 @@ class SemanticMapping(object):
         # race with the kernel's atomic increments).
         st = torch.cuda.current_stream(self.device) if stream is None else torch.cuda.ExternalStream(int(stream), device=self.device)
         cur = torch.cuda.current_stream(self.device)
-        if st.cuda_stream != cur.cuda_stream:
-            st.wait_stream(cur)                                # earlier work of the caller on the current stream (e.g. a frame still reading `dev`)
         with torch.cuda.stream(st):
             points = torch.empty((max(n, 1), 4), dtype=torch.float32, device=self.device)[:n]
             count = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -305,6 +306,9 @@ class SemanticMapping(object):
             cap = max(nbytes, 1 << 22)
             self._pc2_stage = (torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device),
                                torch.cuda.Event(), torch.cuda.Event())
+            if st.cuda_stream != cur.cuda_stream:
+                st.wait_stream(cur)        # the fresh device buffer comes from the CURRENT stream's allocator pool: work queued there may still own the block
+                                           # (only here -- reuse is ordered by the two events, and an unconditional wait removed the overlap a caller passes a stream for)
         host, dev, staged, unpacked = self._pc2_stage
         # The kernel reads what the copy wrote (same stream).  The pinned buffer is reused only after the previous message's copy
         # has executed (`staged`), the shared device staging buffer only after the previous message's KERNEL has (`unpacked`:
