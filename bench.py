@@ -49,6 +49,7 @@ GRID_RES, GRID_HALF = 0.2, 200.0          # 2000 x 2000 cells (BASELINE config C
 PEAK_MFMA16_TFLOPS = 2500.0               # MI355X dense bf16 / f16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+SURVEY_FLOP_PER_FRAME = 1.7768e12          # 888.4 GMAC per 1080 x 1920 forward (whole_frame_frac = this x frames/s/GPU / the f16 MFMA peak)
 
 
 def self_launch(args):
@@ -157,13 +158,30 @@ def main():
         shared = exchange()
     sync()
     elapsed = time.perf_counter() - t0
-    exchange_ms, exchange_bytes = None, None
+    exchange_ms, exchange_bytes, per_rank_fps, exchange_sparse = None, None, None, None
     if world > 1:
+        own_elapsed = elapsed
         exchange_ms = ex0.elapsed_time(ex1)                 # cast + all-reduce on this rank's stream (the frames before it are queued ahead)
         exchange_bytes = int(shared.numel() * shared.element_size())
         t = torch.tensor([elapsed, exchange_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, exchange_ms = float(t[0].item()), float(t[1].item())
+        # outside the timed region: every rank's own frames/s, and the RECORD exchange (all-gather of (cell, delta[C])
+        # records, distributed.reduce_grids_sparse) timed beside the dense all-reduce, so one N-GPU run yields the curve and the comparison
+        fps_all = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(fps_all, torch.tensor([args.steps / own_elapsed], dtype=torch.float64, device=dev))
+        per_rank_fps = [round(float(f.item()), 2) for f in fps_all]
+        sm.global_map(mode="sparse")                        # warm-up (allocations, RCCL channels for the all-gather)
+        sync()
+        sx0, sx1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sx0.record()
+        shared_sparse = sm.global_map(mode="sparse")
+        sx1.record()
+        sync()
+        t2 = torch.tensor([sx0.elapsed_time(sx1)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        exchange_sparse = {"ms": round(float(t2[0].item()), 3), "bytes_sent_per_rank": sm.last_exchange[1],
+                           "max_abs_diff_vs_dense": float((shared_sparse - shared.to(shared_sparse.dtype)).abs().max().item())}
 
     result = None
     if rank == 0:
@@ -204,11 +222,13 @@ def main():
             # the GPU picked by at most this much (relative to max|logit|; bounded by 2 x the logits tolerance)
             "flip_margin_max_rel": None if parity is None else parity["worst"]["flip_margin_max_rel"],
             "exchange_ms": None if exchange_ms is None else round(exchange_ms, 3), "exchange_bytes": exchange_bytes,
+            "exchange_sparse": exchange_sparse, "per_rank_fps": per_rank_fps,
             "config": {"workload": "configs[2] full fuse: seg 1920x1080 + projection + 0.2 m BEV log-odds update, 120k pts, "
                                    "2000x2000x5 f64 grid; weights random-init ResNeXt50-OS8 DeepLabV3+",
                        "precision": args.precision, "frame": [H, W], "points": NPTS, "grid": [sm.map_height, sm.map_width, sm.map_depth],
                        "parallelism": "frame-parallel x%d, 1 grid all-reduce" % world},
-            "roofline": roofline, "parity": parity, "mapping": mapping, "cpu_baseline": cpu_baseline,
+            "roofline": dict(roofline, whole_frame_frac=round(SURVEY_FLOP_PER_FRAME * fps / world / (PEAK_MFMA16_TFLOPS * 1e12), 4)),
+            "parity": parity, "mapping": mapping, "cpu_baseline": cpu_baseline,
             "other_precisions": other,
         }
         print(json.dumps(result), flush=True)
@@ -253,7 +273,9 @@ def gemm_roofline(net, precision):
     peak = PEAK_F32_TFLOPS if precision == "f32" else PEAK_MFMA16_TFLOPS
     achieved = g_fl / g_ms / 1e9
     traffic, traffic_note = pmc_traffic(len(gemm), precision)
+    kernels = kernel_families(prof, net.ops, precision)
     return {"bound": "mfma", "kernel": "k_gemm_mx_pipe (MX GEMMs) / k_gemm_ring / k_gemm: the 1x1 convs, %d launches/frame" % len(gemm), "achieved": round(achieved, 1),
+            "kernels": kernels,
             "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
             "executed_tflops": round(g_exec / g_ms / 1e9, 1), "executed_frac": round(g_exec / g_ms / 1e9 / peak, 4),
             "algorithmic_bytes_per_frame": sum(p["bytes"] for p, _ in gemm),
@@ -262,12 +284,67 @@ def gemm_roofline(net, precision):
                           "tflops": round(seg_fl / seg_ms / 1e9, 1)}}
 
 
+PMC_SUMMARIES = [os.path.join("profiles", r, "pmc_seg_summary_%s.json") for r in ("r05", "r04", "r03", "r02")]
+OP_FAMILY = {"gconv": ("gconv", "hbm"), "dwpw": ("dwpw", "mfma"), "dwconv": ("dwconv", "hbm"), "bottleneck": ("bottleneck", "mfma")}
+KERNEL_FAMILY = (("k_gemm_mx_pipe", "gemm_mx"), ("k_gemm_ring_mx", "gemm_mx"), ("k_gemm", "gemm_ring"), ("k_gconv", "gconv"), ("k_dwpw", "dwpw"),
+                 ("k_dwconv", "dwconv"), ("k_bottleneck", "bottleneck"))
+
+
+def kernel_families(prof, ops, precision):
+    """per kernel family of one frame -- launches, HIP-event milliseconds, algorithmic TFLOP/s and GB/s, the
+    roofline that bounds the family and the fraction of ITS peak reached; from the committed PMC summary (tools/pmc_seg.sh: separate
+    --pmc passes) the HBM traffic over the algorithmic bytes and the matrix cores' busy fraction (SQ_VALU_MFMA_BUSY_CYCLES over kernel
+    cycles x 1024 SIMDs).  gemm_mx = 1x1 convs on the MX kernels (f16 + FP4 passes), gemm_ring = the other 1x1 convs, glue = stem,
+    pooling, bilinear, sub-sampling, GEMVs, arg-max."""
+    fam = {}
+    for p, op in zip(prof, ops):
+        if p["kind"] == "gemm":
+            name, bound = ("gemm_mx" if op.w_split == 2 else "gemm_ring"), "mfma"
+        else:
+            name, bound = OP_FAMILY.get(p["kind"], ("glue", "hbm"))
+        f = fam.setdefault(name, {"family": name, "launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "bound": bound})
+        f["launches"] += 1
+        f["ms"] += p["ms"]
+        f["flops"] += p["flops"]
+        f["bytes"] += p["bytes"]
+    pmc, pmc_file = {}, None
+    for rel in PMC_SUMMARIES:
+        path = os.path.join(ROOT, rel % precision)
+        if os.path.exists(path):
+            pmc_file = rel % precision
+            for r in json.load(open(path)):
+                name = next((f for k, f in KERNEL_FAMILY if r["kernel"].startswith(k)), "glue")
+                a = pmc.setdefault(name, {"bytes": 0.0, "launches": 0, "busy": 0.0, "busy_w": 0.0})
+                a["bytes"] += (r["fetch_MB_per_launch"] + r["write_MB_per_launch"]) * 1048576.0 * r["launches_profiled"]
+                a["launches"] += r["launches_profiled"]
+                if r.get("mfma_busy") is not None:          # weighted by the family's matrix instructions
+                    w = r.get("mfma_insts_per_launch", 0.0) * r["launches_profiled"] + 1e-9
+                    a["busy"] += r["mfma_busy"] * w
+                    a["busy_w"] += w
+            break
+    out = []
+    peak_tf = PEAK_F32_TFLOPS if precision == "f32" else PEAK_MFMA16_TFLOPS
+    for f in sorted(fam.values(), key=lambda f: -f["ms"]):
+        tf, gb = f["flops"] / f["ms"] / 1e9, f["bytes"] / f["ms"] / 1e6
+        row = {"family": f["family"], "launches": f["launches"], "ms": round(f["ms"], 4), "tflops": round(tf, 1), "GBps": round(gb, 1), "bound": f["bound"],
+               "frac_of_bound_peak": round(tf / peak_tf if f["bound"] == "mfma" else gb / PEAK_HBM_GBS, 4),
+               "pmc_over_algorithmic": None, "mfma_busy": None}
+        a = pmc.get(f["family"])
+        if a and a["launches"]:
+            per_frame = a["bytes"] / (a["launches"] / float(f["launches"]))
+            row["pmc_over_algorithmic"] = round(per_frame / f["bytes"], 3) if f["bytes"] else None
+            row["mfma_busy"] = round(a["busy"] / a["busy_w"], 3) if a["busy_w"] > 1e-6 else None
+        out.append(row)
+    return {"families": out, "pmc_summary": pmc_file}
+
+
 def pmc_traffic(n_gemm_launches, precision):
     """HBM bytes per frame moved by the GEMM kernels, from the committed rocprofv3 PMC summary (separate
     --pmc passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
     16-B/lane reads on gfx950).  PMC cannot be collected inside the timed run, so this is read from
     profiles/ (tools/pmc_seg.sh regenerates it); None if no summary for this precision is committed."""
-    for rel in (os.path.join("profiles", "r04", "pmc_seg_summary_%s.json" % precision),
+    for rel in (os.path.join("profiles", "r05", "pmc_seg_summary_%s.json" % precision),
+                os.path.join("profiles", "r04", "pmc_seg_summary_%s.json" % precision),
                 os.path.join("profiles", "r03", "pmc_seg_summary_%s.json" % precision),
                 os.path.join("profiles", "r02", "pmc_seg_summary_%s.json" % precision),
                 os.path.join("profiles", "r01", "pmc_seg_summary.json") if precision == "bf16" else None):

@@ -234,6 +234,38 @@ def gen_network():
                    os.path.join(OUT, "net_blocks.pt"))
         print("blocks ok")
 
+        # round 5: the same two modules at widths the HIP kernels take (256-channel branches, 64-channel K steps), so the
+        # GPU tests compare the KERNELS with the reference modules' outputs directly, not only the oracle with them
+        aspp = AtrousSpatialPyramidPoolingModule(in_channels=256, out_channels=256, atrous_channels=(256, 256, 256, 256),
+                                                 atrous_kernel_size=(1, 3, 3, 3), atrous_dilation=(1, 12, 24, 36))
+        randomise_bn(aspp, gen)
+        aspp.eval()
+
+        def f16_exact(module):        # conv weights that ARE float16 values: the fixture then stores them in half the bytes, exactly
+            for prm in module.parameters():
+                if prm.dim() == 4:
+                    prm.data.copy_(prm.data.to(torch.float16).to(torch.float32))
+
+        def packed(state):
+            return {k: (v.to(torch.float16) if v.dim() == 4 else v) for k, v in state.items()}
+
+        f16_exact(aspp)
+        x = torch.randn(1, 256, 33, 40, generator=gen).to(torch.float16).to(torch.float32)
+        y = aspp(x)
+        torch.save({"state": packed(aspp.state_dict()), "x": x.to(torch.float16), "y": y}, os.path.join(OUT, "net_aspp256.pt"))
+        print("aspp256", tuple(x.shape), "->", tuple(y.shape))
+        dec = Decoder(in_channels=256, out_channels=19, low_level_in_channels=256, low_level_out_channels=256,
+                      refine_channels=(256, 256), refine_kernel_size=(3, 3))
+        randomise_bn(dec, gen)
+        dec.eval()
+        f16_exact(dec)
+        f = torch.randn(1, 256, 12, 15, generator=gen).to(torch.float16).to(torch.float32)
+        low = torch.randn(1, 256, 24, 30, generator=gen).to(torch.float16).to(torch.float32)
+        y = dec(f, low)
+        torch.save({"state": packed(dec.state_dict()), "feature": f.to(torch.float16), "low": low.to(torch.float16), "y": y},
+                   os.path.join(OUT, "net_decoder256.pt"))
+        print("decoder256", tuple(f.shape), tuple(low.shape), "->", tuple(y.shape))
+
 
 def gen_render():
     """src/renderer.py (numpy + scipy only) on a grid from the mapping fixtures plus hand-made corner cases."""

@@ -37,13 +37,22 @@ def _cfg(cm):
 
 
 def _worker(rank, world, port, cm_kind, q):
+    try:
+        _worker_body(rank, world, port, cm_kind, q)
+    except Exception as e:            # the parent must not wait for a result that never comes
+        import traceback
+        q.put(("error", "rank %d: %s" % (rank, traceback.format_exc(limit=3))))
+        raise
+
+
+def _worker_body(rank, world, port, cm_kind, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import mapping_oracle as mo
     from vision_semantic_segmentation_amd import synthetic as syn
-    from vision_semantic_segmentation_amd.distributed import reduce_grids, shard_frames
+    from vision_semantic_segmentation_amd.distributed import reduce_grids, reduce_grids_auto, reduce_grids_sparse, shard_frames
     frames, P = _frames(6)
     cm = np.eye(5) if cm_kind == "eye" else syn.log_confusion(5)
     cfg = _cfg(cm)
@@ -58,20 +67,51 @@ def _worker(rank, world, port, cm_kind, q):
     # the float32 exchange copy (what bench.py --gpus N sends: half the payload)
     total32 = reduce_grids(private, exchange_dtype=torch.float32)
     assert total32.dtype == torch.float32 and torch.equal(private, torch.from_numpy(grid))
+    # round 5: the record exchange -- all-gather of (cell, delta[C]) -- gives the same grid
+    sparse, sent = reduce_grids_sparse(private)
+    assert sparse.dtype == private.dtype and torch.equal(private, torch.from_numpy(grid))
+    # the ranks' float32 addends summed in the grid's own float64: identity-CM grids (small integers) equal the dense result exactly,
+    # log-CM grids differ from the float32 all-reduce by its one rounding of the SUM (the record exchange is the more accurate one)
+    if cm_kind == "eye":
+        assert torch.equal(sparse, total32.to(torch.float64)) and torch.equal(sparse, total)
+    else:
+        assert float((sparse - total).abs().max()) <= 2e-7 * float(total.abs().max())
+    touched = int((grid != 0).any(axis=2).sum())
+    assert 0 < sent < 0.2 * total32.numel() * 4 and sent >= touched * 24
+    auto, used, _ = reduce_grids_auto(private, max_fraction=0.5)
+    assert used == "sparse" and torch.equal(auto, sparse)
+    auto_d, used_d, sent_d = reduce_grids_auto(private, max_fraction=1e-6)
+    assert used_d == "dense" and torch.equal(auto_d, total32.to(torch.float64)) and sent_d == total32.numel() * 4
+    assert float((auto_d - sparse).abs().max()) <= 2e-7 * max(1.0, float(total.abs().max()))
     if rank == 0:
         assert torch.equal(root_only, total)
-        q.put((mine, total.numpy(), total32.numpy()))
+        q.put(("ok", (mine, total.numpy(), total32.numpy())))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(cm_kind, port):
+def _run(cm_kind, port=None):
+    import queue
+    import socket
+
+    import pytest
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
+    with socket.socket() as sock:            # a free port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, cm_kind, q)) for r in range(2)]
     for p in procs:
         p.start()
-    mine, total, total32 = q.get()
+    try:
+        status, payload = q.get(timeout=240)
+    except queue.Empty:
+        status, payload = "error", "no result within 240 s (exit codes %r)" % [p.exitcode for p in procs]
+    if status != "ok":
+        for p in procs:
+            p.terminate()
+        pytest.fail(payload)
+    mine, total, total32 = payload
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

@@ -203,6 +203,14 @@ def _two_rank_worker(rank, world, port, q):
         total = sm.global_map()                                   # all-reduce (sum) of a copy of the private DEVICE grid
         total32 = sm.global_map(exchange_dtype=torch.float32)
         assert total.is_cuda and torch.equal(sm.map_dev, private)
+        # round 5: the record exchange (all-gather of (cell, delta[C]) records) gives the same shared grid -- each rank's float32 addends
+        # summed in float64 -- and sends a fraction of the dense payload; "auto" picks it here (a camera frustum touches a few % of the cells)
+        sparse = sm.global_map(mode="sparse")
+        assert sparse.is_cuda and sparse.dtype == private.dtype and torch.equal(sm.map_dev, private)
+        assert float((sparse - total).abs().max()) <= 2e-7 * float(total.abs().max()) and sm.last_exchange[0] == "sparse"
+        assert 0 < sm.last_exchange[1] < 0.25 * total32.numel() * 4
+        auto = sm.global_map(mode="auto")
+        assert sm.last_exchange[0] == "sparse" and torch.equal(auto, sparse)
         if rank == 0:
             q.put(("ok", (private.cpu().numpy(), total.cpu().numpy(), total32.cpu().numpy())))
         dist.barrier()

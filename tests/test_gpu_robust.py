@@ -53,6 +53,8 @@ def test_mixed_logits_on_heavy_tailed_weights(wseed, cuda_device):
         del net
     print("heavy-tailed weights %d at %dx%d: f32 %.2e, mixed %.2e of max|logit| (%.1f), arg-max agreement %.4f" % (wseed, h, w, errs["f32"], errs["mixed"], scale, agree))
     assert errs["f32"] <= 1e-3
+    if wseed >= 2:                     # (the self-check costs five plan builds and twenty forwards: on two of the four draws)
+        return
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
         seg = SemanticSegmentation(_cfg(), device=cuda_device, state_dict=st)

@@ -37,3 +37,15 @@ def test_conv_blocks_match_reference_modules():
     st = {"d." + k: v for k, v in g["dw_state"].items()}
     y = no.depthwise_separable(g["x"], st, "d", padding=3, dilation=3, pointwise_relu=False)
     assert torch.allclose(y, g["y_dw"], rtol=0, atol=1e-6)
+
+
+def test_oracle_matches_the_kernel_width_fixtures(golden_dir):
+    """round 5: the same two reference modules at 256-channel widths (what tests/test_gpu_modules.py feeds the HIP kernels)"""
+    a = torch.load(os.path.join(golden_dir, "net_aspp256.pt"), map_location="cpu", weights_only=True)
+    st = {"aspp." + k: v.float() for k, v in a["state"].items()}
+    y = no.aspp_forward(st, a["x"].float())
+    assert float((y - a["y"]).abs().max() / a["y"].abs().max()) <= 1e-6
+    d = torch.load(os.path.join(golden_dir, "net_decoder256.pt"), map_location="cpu", weights_only=True)
+    st = {"decoder." + k: v.float() for k, v in d["state"].items()}
+    y = no.decoder_forward(st, d["feature"].float(), d["low"].float())
+    assert float((y - d["y"]).abs().max() / d["y"].abs().max()) <= 1e-6

@@ -466,7 +466,7 @@ class SegNet(object):
     MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx", "dw_exact", "layer1_lo", "fuse_block")    # keyword switches of the "mixed" mode
 
     def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8, fuse_dwpw=True, raw_frame=None,
-                 **mixed_opts):
+                 part=None, **mixed_opts):
         """raw_frame = (src_h, src_w): the plan's input is the RAW BGR camera frame and the node's pre-processing
         (vision_semantic_segmentation_node.py:83-98: BGR->RGB, undistort, INTER_AREA by src_w // width) runs inside the stem's loader
         (16-bit precisions); ``set_camera`` chooses the camera model, ``forward`` takes the raw frame."""
@@ -512,7 +512,14 @@ class SegNet(object):
         self.ops = []
         self.op_names = []
         self._plan = C.c_void_p()
-        self._build(state)
+        # part = None: the whole network.  ("aspp", C): height x width is the FEATURE map, `state` an ASPP module's state dict ("aspp." keys);
+        # ("decoder", C_feature, C_low): height x width the feature map, the low-level map twice that -- sub-plans for the tests that compare
+        # the HIP kernels with the reference MODULES' outputs (tests/golden/net_aspp256.pt, net_decoder256.pt)
+        self.part = part
+        if part is None:
+            self._build(state)
+        else:
+            self._build_part(state)
         arr = (AvlSegOp * len(self.ops))(*self.ops)
         _lib.check(_lib.lib().avl_seg_plan_create(arr, len(self.ops), C.byref(self._plan)), "avl_seg_plan_create")
 
@@ -846,10 +853,46 @@ class SegNet(object):
             if li == 1:
                 low, low_hw, low_c = x, hw, cin           # low_features = layer1 output (resnet.py:33-34)
 
-        feat, fhw, fc = x, hw, cin
-        M = fhw[0] * fhw[1]
+        aspp, aspp_out = self._emit_aspp(st, x, hw, cin)
+        self._emit_decoder(st, aspp, hw, aspp_out, low, low_hw, low_c)
 
-        # ---- ASPP (aspp.py:79-95), dilations forced to 1,12,24,36 for OS8 (deeplab_v3_plus.py:33-34)
+    def _part_input(self, rows, ch):
+        """a sub-plan's input activation (hi [+ lo] planes of the activation type) -> (Act, setter(float tensor [ch, h, w]))"""
+        a = self._act(rows, ch, split=self.mixed)
+
+        def put(x):
+            m = x.permute(1, 2, 0).reshape(rows, ch).to(torch.float64)
+            hi = m.to(self.act_dtype)
+            a.hi[:rows].copy_(hi.to(self.device))
+            if a.lo is not None:
+                a.lo[:rows].copy_((m - hi.to(torch.float64)).to(self.act_dtype).to(self.device))
+        return a, put
+
+    def _build_part(self, st):
+        H, W = self.H, self.W
+        self.zero_page = torch.zeros(64, dtype=torch.uint8, device=self.device)
+        self._keep.append(self.zero_page)
+        if self.part[0] == "aspp":
+            feat, self.set_feature = self._part_input(H * W, self.part[1])
+            self.part_out, self.part_out_c = self._emit_aspp(st, feat, (H, W), self.part[1])
+            self.out_h, self.out_w = H, W
+        else:
+            feat, self.set_feature = self._part_input(H * W, self.part[1])
+            low, self.set_low = self._part_input(4 * H * W, self.part[2])
+            self._emit_decoder(st, feat, (H, W), self.part[1], low, (2 * H, 2 * W), self.part[2])
+
+    def part_output(self):
+        """float32 [C, h, w] of a ("aspp", ...) sub-plan's output (hi + lo planes)"""
+        a, rows = self.part_out, self.out_h * self.out_w
+        y = a.hi[:rows, :self.part_out_c].float()
+        if a.lo is not None:
+            y = y + a.lo[:rows, :self.part_out_c].float()
+        return y.reshape(self.out_h, self.out_w, self.part_out_c).permute(2, 0, 1)
+
+    def _emit_aspp(self, st, feat, fhw, fc):
+        """ASPP (aspp.py:79-95), dilations forced to 1,12,24,36 for OS8 (deeplab_v3_plus.py:33-34) -> (output Act, its channels)"""
+        dev = self.device
+        M = fhw[0] * fhw[1]
         dil = (1, 12, 24, 36)
         branches = []
         i = 0
@@ -904,8 +947,11 @@ class SegNet(object):
         self._gemm("aspp.conv", cat, fhw, ncat, wp_[:, :ncat], None, aspp, bias_dev=proj_bias)       # dropout = identity (eval)
         self._release(cat)
         self._release(feat)
+        return aspp, aspp_out
 
-        # ---- decoder (decoder.py:45-51)
+    def _emit_decoder(self, st, aspp, fhw, aspp_out, low, low_hw, low_c):
+        """decoder (decoder.py:45-51) -> logits_buf / labels_buf"""
+        dev = self.device
         w, b = fold_bn(st, "decoder.low_level_conv.conv.weight", "decoder.low_level_conv.bn")
         low_out = w.shape[0]
         Ml = low_hw[0] * low_hw[1]
@@ -980,6 +1026,7 @@ class SegNet(object):
         """image_u8: CUDA/CPU uint8 [H,W,3] RGB -- or, for a raw_frame plan, the [src_h,src_w,3] BGR camera frame -- (copied
         into the plan's input buffer) or None to reuse it."""
         if image_u8 is not None:
+            assert self.part is None, "a sub-plan takes its inputs through set_feature / set_low"
             if not isinstance(image_u8, torch.Tensor):
                 image_u8 = torch.from_numpy(np.ascontiguousarray(image_u8))
             assert tuple(image_u8.shape) == tuple(self.image.shape) and image_u8.dtype == torch.uint8
