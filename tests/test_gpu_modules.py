@@ -25,7 +25,6 @@ def test_aspp_kernels_against_the_reference_module(precision, bar, golden_dir, c
     st = {"aspp." + k: v for k, v in d["state"].items() if not k.endswith("num_batches_tracked")}
     x, y = d["x"][0], d["y"][0]
     net = SegNet(st, x.shape[1], x.shape[2], precision=precision, device=cuda_device, part=("aspp", x.shape[0]))
-    assert sum(1 for n in net.op_names if n.startswith("aspp.module_pyramid")) == 4
     net.set_feature(x)
     net.forward()
     torch.cuda.synchronize()

@@ -138,3 +138,26 @@ def test_self_check_switch_is_parsed_strictly():
         _strict_bool("maybe", "x")
     with pytest.raises(ValueError):
         _strict_bool(2, "x")
+
+
+def test_self_check_decision_table():
+    """SemanticSegmentation.decide_rung without a GPU: best passing rung; nothing passes -> f32 / raise / best finite plan; a NaN error or
+    an Inf in some tensor never 'passes' and is never kept by 'warn'"""
+    import pytest
+    from vision_semantic_segmentation_amd.semantic_segmentation import SemanticSegmentation as S
+    nan = float("nan")
+
+    def t(rung, err, finite=True, bad=(), passes=None):
+        return {"rung": rung, "rel_err": err, "finite": finite, "nonfinite_ops": list(bad),
+                "passes": (finite and not bad and err <= 1e-3) if passes is None else passes}
+    assert S.decide_rung([t("mixed", 6e-4)], "f32") == ("mixed", 6e-4, None)
+    assert S.decide_rung([t("mixed", 9.5e-4), t("mixed+lo", 9e-4), t("split16", 9.9e-4)], "f32")[0] == "mixed+lo"
+    assert S.decide_rung([t("mixed", 5e-2), t("mixed+lo", 4e-2), t("split16", 8e-4)], "raise")[0] == "split16"
+    bad3 = [t("mixed", 0.25, bad=["backbone.layer2.1.conv1"]), t("mixed+lo", nan, finite=False), t("split16", 3e-2)]
+    rung, err, warn = S.decide_rung(bad3, "f32")
+    assert rung == "f32" and "no 16-bit plan" in warn and "Inf/NaN in backbone.layer2.1.conv1" in warn
+    with pytest.raises(RuntimeError, match="no 16-bit plan"):
+        S.decide_rung(bad3, "raise")
+    rung, err, warn = S.decide_rung(bad3, "warn")
+    assert rung == "split16" and err == 3e-2 and "keeping" in warn
+    assert S.decide_rung(bad3[:2], "warn")[0] == "f32"                 # nothing finite to keep

@@ -442,6 +442,43 @@ def pack_mx_weights(w):
     return hi, torch.cat([ql.reshape(-1), permute_w_scales(sl).reshape(-1), qh.reshape(-1), permute_w_scales(sh).reshape(-1)])
 
 
+# Packed weights are a pure function of (the state dict's content, the op, the packing variant): building the plan for another image size,
+# or the five plans of the load-time self-check, repeats the float64 folding and -- far slower -- the host-side FP4 quantisation of the MX
+# bundles.  Cached on the host, keyed by a fingerprint of the state dict (not its id(): that can be reused after a free), bounded in bytes.
+_PACK_CACHE = {}
+_PACK_CACHE_BYTES = [0]
+PACK_CACHE_LIMIT = 3 << 30
+
+
+def state_fingerprint(state):
+    """(sum, sum of squares, number of elements) over all tensors, float64: two different weight sets do not share it"""
+    s1 = s2 = 0.0
+    n = 0
+    for k in sorted(state):
+        t = state[k]
+        if torch.is_tensor(t) and t.is_floating_point():
+            t64 = t.detach().to(torch.float64)
+            s1 += float(t64.sum())
+            s2 += float((t64 * t64).sum()) * (1.0 + 1e-3 * (hash(k) % 97))
+            n += t.numel()
+    return (s1, s2, n)
+
+
+def _cached_pack(key, fn):
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        return hit
+    out = fn()
+    ts = out if isinstance(out, (tuple, list)) else (out,)
+    nbytes = sum(t.numel() * t.element_size() for t in ts if torch.is_tensor(t))
+    if _PACK_CACHE_BYTES[0] + nbytes > PACK_CACHE_LIMIT:
+        _PACK_CACHE.clear()
+        _PACK_CACHE_BYTES[0] = 0
+    _PACK_CACHE[key] = out
+    _PACK_CACHE_BYTES[0] += nbytes
+    return out
+
+
 class Act(object):
     """An activation [rows][ch]: one plane of the activation type, or ("mixed" precision) two float16 planes hi + lo of the
     same shape."""
@@ -512,6 +549,7 @@ class SegNet(object):
         self.ops = []
         self.op_names = []
         self._plan = C.c_void_p()
+        self._fp = state_fingerprint(state)
         # part = None: the whole network.  ("aspp", C): height x width is the FEATURE map, `state` an ASPP module's state dict ("aspp." keys);
         # ("decoder", C_feature, C_low): height x width the feature map, the low-level map twice that -- sub-plans for the tests that compare
         # the HIP kernels with the reference MODULES' outputs (tests/golden/net_aspp256.pt, net_decoder256.pt)
@@ -606,12 +644,13 @@ class SegNet(object):
         assert src2 is None or use_mx, "%s: a second input needs the MX GEMM" % name
         w_mx = None
         if use_mx:
-            whi, bundle = pack_mx_weights(wp)
+            whi, bundle = _cached_pack((self._fp, name, "mx", tuple(wp.shape)), lambda: pack_mx_weights(wp))
             wdev = self._dev(whi, torch.float16)
             w_mx = bundle.to(self.device)
             self._keep.append(w_mx)
         elif self.mixed:
-            wdev = self._dev(pack_split_rows(wp, 3 if in_lo else 2), torch.float16)
+            nsub = 3 if in_lo else 2
+            wdev = self._dev(_cached_pack((self._fp, name, "split", nsub, tuple(wp.shape)), lambda: pack_split_rows(wp, nsub)), torch.float16)
         else:
             wdev = self._dev(wp, self.act_dtype)
         if bias_dev is None:
@@ -660,7 +699,8 @@ class SegNet(object):
         if (p + ".downsample.0.weight") in st:
             wd, bd = fold_bn(st, p + ".downsample.0.weight", p + ".downsample.1")
             wd, b3 = wd.reshape(cout, cin), b3 + bd
-        p1, p2, p3 = (self._dev(t, torch.float16) for t in pack_bottleneck(w1.reshape(width, cin), w2, w3.reshape(cout, width), wd, GROUPS))
+        p1, p2, p3 = (self._dev(t, torch.float16) for t in _cached_pack(
+            (self._fp, p, "bottleneck"), lambda: pack_bottleneck(w1.reshape(width, cin), w2, w3.reshape(cout, width), wd, GROUPS)))
         bias = self._dev(torch.cat([b1, b2, b3]), torch.float32)
         ip, ild, irows = self._view(x)
         op_, old, orows = self._view(y)
@@ -785,7 +825,7 @@ class SegNet(object):
                 wsplit = int(self.mixed)
                 extra_g = {}
                 if gconv_mx:
-                    frag_hi, bundle = pack_gconv_mx(w, GROUPS)
+                    frag_hi, bundle = _cached_pack((self._fp, p + ".conv2", "gconv_mx"), lambda: pack_gconv_mx(w, GROUPS))
                     wg_d, layout, wsplit = self._dev(frag_hi.reshape(-1), torch.float16), 1, 2
                     wb = bundle.to(self.device)
                     self._keep.append(wb)
@@ -1033,7 +1073,7 @@ class SegNet(object):
             self.image.copy_(image_u8, non_blocking=True)
         s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
         _lib.check(_lib.lib().avl_seg_plan_run(self._plan, C.c_void_p(s)), "avl_seg_plan_run")
-        return self.labels
+        return self.labels if hasattr(self, "labels_buf") else None          # (an ASPP sub-plan has no classifier: part_output())
 
     def capture_graph(self):
         """Record the plan into a hipGraph (one launch per forward afterwards).  Runs the plan once first, on a

@@ -101,6 +101,26 @@ class SemanticSegmentation(object):
                       layer1_lo=(rung == "mixed+lo"), **kw)
 
     @staticmethod
+    def decide_rung(tried, on_fail, n_frames=4):
+        """The self-check's decision, apart from its measurements: `tried` = [{"rung", "rel_err", "finite", "nonfinite_ops", "passes"}] in
+        ladder order -> (rung to use, its error, warning text or None).  The best PASSING rung wins; when none passes: on_fail "f32" ->
+        the fp32 plan, "raise" -> RuntimeError, "warn" -> the best finite 16-bit plan (fp32 if there is none)."""
+        ok = [t for t in tried if t["passes"]]
+        if ok:
+            t = min(ok, key=lambda t: t["rel_err"])
+            return t["rung"], t["rel_err"], None
+        summary = "; ".join("%s: %s" % (t["rung"], ("%.2e" % t["rel_err"]) if t["finite"] and not t["nonfinite_ops"]
+                                        else "Inf/NaN in " + ", ".join(t["nonfinite_ops"] or ["the logits"])) for t in tried)
+        msg = ("mixed precision: no 16-bit plan reproduces the fp32 logits of these weights within 1e-3 on %d frames (%s)" % (n_frames, summary))
+        if on_fail == "raise":
+            raise RuntimeError(msg)
+        usable = [t for t in tried if t["finite"] and not t["nonfinite_ops"] and t["rel_err"] == t["rel_err"]]
+        if on_fail == "warn" and usable:
+            t = min(usable, key=lambda t: t["rel_err"])
+            return t["rung"], t["rel_err"], msg + "; keeping '%s' (MODEL.MIXED_ON_FAIL = 'warn')" % t["rung"]
+        return "f32", 0.0, msg + "; using the fp32 plan (4x slower)"
+
+    @staticmethod
     def check_frames(h, w, seed=1, n_noise=3):
         """The self-check's frames: `n_noise` uniform-noise frames and one smooth frame (low-frequency colour ramps + a few blobs: real
         camera frames excite far fewer high-frequency channels than noise does)."""
@@ -132,7 +152,7 @@ class SemanticSegmentation(object):
         del ref
         if not all(bool(torch.isfinite(r).all()) for r in refs):
             raise RuntimeError("the checkpoint's logits are not finite even in fp32: %s" % (self.cfg.MODEL.WEIGHT or "<state_dict>"))
-        tried, best = [], None
+        tried = []
         start = self.LADDER.index(self._rung)
         for rung in self.LADDER[start:-1]:
             net = self._build(h, w, rung)
@@ -147,29 +167,13 @@ class SemanticSegmentation(object):
             del net
             ok = finite and not bad and (err <= 1e-3)
             tried.append({"rung": rung, "rel_err": err, "finite": finite, "nonfinite_ops": sorted(bad)[:4], "passes": ok})
-            if ok and (best is None or err < best[1]):
-                best = (rung, err)
             if ok and err <= threshold:
                 break
         torch.cuda.empty_cache()
         self.mixed_check = {"size": (h, w), "threshold": threshold, "frames": len(frames), "tried": tried}
-        if best is not None:
-            self._rung, err = best
-        else:
-            summary = "; ".join("%s: %s" % (t["rung"], ("%.2e" % t["rel_err"]) if t["finite"] and not t["nonfinite_ops"]
-                                            else "Inf/NaN in " + ", ".join(t["nonfinite_ops"])) for t in tried)
-            msg = ("mixed precision: no 16-bit plan reproduces the fp32 logits of these weights within 1e-3 on %d frames (%s)"
-                   % (len(frames), summary))
-            if self.on_fail == "raise":
-                raise RuntimeError(msg)
-            usable = [t for t in tried if t["finite"] and not t["nonfinite_ops"]]
-            if self.on_fail == "warn" and usable:
-                t = min(usable, key=lambda t: t["rel_err"])
-                self._rung, err = t["rung"], t["rel_err"]
-                warnings.warn(msg + "; keeping '%s' (MODEL.MIXED_ON_FAIL = 'warn')" % self._rung)
-            else:
-                self._rung, err = "f32", 0.0
-                warnings.warn(msg + "; using the fp32 plan (4x slower)")
+        self._rung, err, warning = self.decide_rung(tried, self.on_fail, len(frames))
+        if warning:
+            warnings.warn(warning)
         self._layer1_lo = self._rung != "mixed"
         self.mixed_check.update(rung=self._rung, layer1_lo=self._layer1_lo, rel_err=err)
         return self.mixed_check
