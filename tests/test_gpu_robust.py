@@ -24,10 +24,11 @@ def _cfg(precision="mixed"):
 def test_mixed_logits_on_heavy_tailed_weights(wseed, cuda_device):
     """MEASURED (profiles/r05/heavy_tail_sweep.log): with CALIBRATED BatchNorm statistics -- every BN subtracts the mean of
     the tensor it normalises, as a trained checkpoint's does; the seeded `random_state_dict` does not -- every rounding is amplified:
-    the fp32-input HIP path itself moves to 3e-5 ... 8e-4 of the torch-CPU oracle (2e-6 on the seeded draws), and EVERY 16-bit plan
-    lands at 3e-2 ... 2e-1 (mixed about where plain f16 is: its FP4 lo parts and single-plane tensors are no better than f16 once the
-    common mode is gone).  What this test pins is therefore the safety net: such weights never reach the labels through a 16-bit plan --
-    the self-check measures it and falls back to the fp32 plan."""
+    the fp32-input HIP path itself moves to 3e-5 ... 8e-4 of the torch-CPU oracle (2e-6 on the seeded draws), and every plan with an
+    f16-class rounding anywhere lands at 3e-2 ... 2e-1 (mixed about where plain f16 is: its FP4 lo parts and single-plane tensors are
+    no better than f16 once the common mode is gone).  Only the COMPLETE hi + lo pipeline ("split16", tests/test_gpu_fullsplit.py) holds
+    1e-3 there.  What this test pins is the safety net: such weights never reach the labels through a plan that misses the bound -- the
+    self-check measures it and moves down the ladder (to split16: 145 frames/s at 1080p against mixed's 215 and fp32's 50)."""
     import warnings
 
     import torch
@@ -60,9 +61,8 @@ def test_mixed_logits_on_heavy_tailed_weights(wseed, cuda_device):
         seg = SemanticSegmentation(_cfg(), device=cuda_device, state_dict=st)
         chk = seg.check_mixed_against_f32(h, w)
     print("   self-check:", [(t["rung"], "%.2e" % t["rel_err"], t["passes"]) for t in chk["tried"]], "->", chk["rung"])
-    assert chk["rung"] in seg.LADDER and chk["rel_err"] <= 1e-3
-    if chk["rung"] == "f32":
-        assert errs["mixed"] > 1e-3 and any("no 16-bit plan" in str(c.message) for c in caught)
+    assert chk["rung"] == "split16" and chk["rel_err"] <= 1e-3 and errs["mixed"] > 1e-3 and not caught
+    assert [t["passes"] for t in chk["tried"]] == [False, False, True]
     got = seg.logits(img).float().cpu()                                  # (another frame than the check's four)
     assert float((got - ref).abs().max()) / scale <= max(1.2e-3, 1.5 * errs["f32"])
 

@@ -54,9 +54,12 @@ __global__ void __launch_bounds__(kThreads) k_stem(const unsigned char* __restri
 }
 
 // --------------------------------------------------------------------------------------- maxpool
+// Split planes (in_lo / out_lo, f16): the maximum is taken over the VALUES hi + lo (exact in fp32: 22 bits), and the winner is split again --
+// which reproduces that input's own (hi, lo) pair.
 template <typename T>
 __global__ void __launch_bounds__(kThreads) k_maxpool(const T* __restrict__ in, int H, int W, int C, int in_ld,
-                                                     T* __restrict__ out, int OH, int OW, int out_ld) {
+                                                     T* __restrict__ out, int OH, int OW, int out_ld,
+                                                     const T* __restrict__ in_lo = nullptr, T* __restrict__ out_lo = nullptr) {
     const int c8n = C / 8;
     const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
     if (idx >= (long long)OH * OW * c8n) return;
@@ -73,11 +76,25 @@ __global__ void __launch_bounds__(kThreads) k_maxpool(const T* __restrict__ in, 
             if (ix < 0 || ix >= W) continue;
             float v[8];
             Vec8<T>::load(in + ((long long)iy * W + ix) * in_ld + c8 * 8, v);
+            if (in_lo) {
+                float l[8];
+                Vec8<T>::load(in_lo + ((long long)iy * W + ix) * in_ld + c8 * 8, l);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += l[i];
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], v[i]);
         }
     }
-    Vec8<T>::store(out + (long long)pix * out_ld + c8 * 8, m);
+    if (out_lo) {
+        float h[8], l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { h[i] = to_f32(from_f32<T>(m[i])); l[i] = m[i] - h[i]; }
+        Vec8<T>::store(out + (long long)pix * out_ld + c8 * 8, h);
+        Vec8<T>::store(out_lo + (long long)pix * out_ld + c8 * 8, l);
+    } else {
+        Vec8<T>::store(out + (long long)pix * out_ld + c8 * 8, m);
+    }
 }
 
 // ------------------------------------------------------------------------------- grouped 3x3 conv
@@ -569,7 +586,8 @@ int launch_typed(const avl_seg_op& op, hipStream_t s) {
             break;
         case AVL_OP_MAXPOOL:
             hipLaunchKernelGGL(k_maxpool<T>, dim3(blocks_for((long long)op.out_h * op.out_w * (op.in_c / 8))), dim3(kThreads), 0, s,
-                               in, op.in_h, op.in_w, op.in_c, op.in_ld, out, op.out_h, op.out_w, op.out_ld);
+                               in, op.in_h, op.in_w, op.in_c, op.in_ld, out, op.out_h, op.out_w, op.out_ld, static_cast<const T*>(op.in_lo),
+                               static_cast<T*>(op.out_lo));
             break;
         case AVL_OP_GCONV: {
             const int cg = op.in_c / op.groups;
@@ -718,8 +736,10 @@ int validate_conv_op(const avl_seg_op& op) {
     if (op.in_lo || op.out_lo || op.in2_lo) {
         // split (hi + lo) planes: same shape and stride as the high plane; f16 only
         AVL_REQUIRE(op.dtype == AVL_F16 && !op.in2_lo, "op %d: split planes need AVL_F16 (and no in2_lo)", op.kind);
-        AVL_REQUIRE(op.kind == AVL_OP_BILINEAR || op.kind == AVL_OP_DWCONV || (op.kind == AVL_OP_GCONV && op.w_layout == 1),
+        AVL_REQUIRE(op.kind == AVL_OP_BILINEAR || op.kind == AVL_OP_DWCONV || (op.kind == AVL_OP_GCONV && op.w_layout == 1) || op.kind == AVL_OP_MAXPOOL ||
+                        (op.kind == AVL_OP_STEM && op.w_layout == 1 && op.w_split == 1 && !op.in_lo),
                     "op %d does not take split planes", op.kind);
+        AVL_REQUIRE(op.kind != AVL_OP_MAXPOOL || (op.in_lo != nullptr) == (op.out_lo != nullptr), "maxpool: both sides split or none");
         AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.in_lo) | reinterpret_cast<uintptr_t>(op.out_lo)) % 16 == 0, "op %d: unaligned low planes", op.kind);
     }
     switch (op.kind) {

@@ -25,6 +25,7 @@ constexpr int CC = 64;          // channels per workgroup (2 windows of 32)
 template <typename HT>
 struct GconvArgs {
     const HT* in;
+    const HT* in_lo;      // XS (split input: the complete hi + lo pipeline): the input's lo plane, same shape and stride
     const HT* w;          // [window][nj 2][tap 9][i 16][ci 32]
     const float* bias;   // [C]
     HT* out;
@@ -64,8 +65,11 @@ struct GconvArgs {
 // to the 18 f16 ones (the f16-only form of split weights needs 36 and cannot correct for xl at all).  The LDS tile buffer
 // then also holds the FP4 tiles (plane 2 x window 2, 16 B per pixel, 64 pixels per DMA instruction) and one scale dword per
 // pixel and plane.
-template <typename HT, int WS, int NJ>      // NJ = tile height / 2: sub-tiles per wave and tile
+// XS (WS = 1 only): the input is split too (f16 planes hi + lo): a second f16 tile in LDS and a third pass Wh . xl per tap -- every
+// operand of the 3x3 then carries ~22 bits (the complete-split plan of MODEL.MIXED_SELF_CHECK's ladder).
+template <typename HT, int WS, int NJ, bool XS = false>      // NJ = tile height / 2: sub-tiles per wave and tile
 __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
+    static_assert(!XS || WS == 1, "a split input goes with split weights");
     typedef typename Half16<HT>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -96,6 +100,7 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
     const int n64 = (npix + 63) >> 6;
     const int QBASE = ngroups * 1024, QT = n64 * 1024, SBASE = QBASE + 4 * QT, ST = n64 * 256;
     const bool has_lo = WS == 2 && p.xq[1] != nullptr;
+    const int LOBASE = ngroups * 1024;            // XS: the lo plane's tile behind the hi plane's
 
     // ---- stage one input tile (+halo) by LDS-DMA: one wave-instruction = 8 pixels x 128 B, all of a wave's transfers in
     // flight at once.  The DMA writes LDS lane-linearly, so the chunk swizzle goes on the SOURCE address.  Pixels outside
@@ -123,6 +128,7 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
             // uniform base (plane + channel chunk) + 32-bit lane offset
             const unsigned voff = ((unsigned)(cy * p.W + cx) * (unsigned)p.in_ld + ((cphys ^ (pix & 7)) << 3)) * (unsigned)sizeof(HT);
             glds16_saddr(p.in + c0, voff, lds0 + buf * p.tile_bytes + gi * 1024);
+            if constexpr (XS) glds16_saddr(p.in_lo + c0, voff, lds0 + buf * p.tile_bytes + LOBASE + gi * 1024);
             oob |= outside << it;
         }
         if constexpr (WS == 2) {
@@ -205,7 +211,10 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
         if (mask) {
             int it = 0;
             for (int gi = wave; gi < ngroups; gi += 8, ++it)
-                if ((mask >> it) & 1u) *reinterpret_cast<uint4*>(lds + b * p.tile_bytes + gi * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+                if ((mask >> it) & 1u) {
+                    *reinterpret_cast<uint4*>(lds + b * p.tile_bytes + gi * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+                    if constexpr (XS) *reinterpret_cast<uint4*>(lds + b * p.tile_bytes + LOBASE + gi * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+                }
             if constexpr (WS == 2) {
                 const int pwbits = has_lo ? 2 : 1;
                 it = 16;
@@ -330,6 +339,27 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
                         acc1 = Half16<HT>::mfma(wf[1][9 + t], a[t], acc1);
                     }
                 }
+                if constexpr (XS) {          // Wh . xl: the same nine addresses in the lo tile (a[] is reused)
+                    if constexpr (HOIST) {
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) a[t] = *reinterpret_cast<const v8*>(tile + LOBASE + toff[j][t]);
+                    } else {
+                        const int st = part + 4 * j;
+                        int frv = fr;
+                        asm volatile("" : "+v"(frv));
+                        const int sy = st >> 1, sx = (st & 1) * 16 + frv;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) {
+                            const int pix = (sy * s + (t / 3) * d) * in_tw + sx * s + (t % 3) * d;
+                            a[t] = *reinterpret_cast<const v8*>(tile + LOBASE + pix * 128 + ((chunk_in ^ (pix & 7)) << 4));
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        acc0 = Half16<HT>::mfma(wf[0][t], a[t], acc0);
+                        acc1 = Half16<HT>::mfma(wf[1][t], a[t], acc1);
+                    }
+                }
             }
             acc[j][0] = acc0; acc[j][1] = acc1;
             __builtin_amdgcn_sched_barrier(0);      // keep the next sub-tile's nine fragments out of this one's registers
@@ -437,10 +467,10 @@ int gconv_mfma_lds_bytes(int stride, int dil, int& th) {
     return ((in_th * in_tw + 7) / 8) * 1024;      // whole 8-pixel DMA groups
 }
 
-static int gconv_tile_bytes(int stride, int dil, int th, bool mx = false) {
+static int gconv_tile_bytes(int stride, int dil, int th, bool mx = false, bool xs = false) {
     const int in_th = (th - 1) * stride + 2 * dil + 1, in_tw = (TW - 1) * stride + 2 * dil + 1;
     const int npix = in_th * in_tw, n64 = (npix + 63) / 64;
-    return ((npix + 7) / 8) * 1024 + (mx ? 4 * n64 * 1024 + 2 * n64 * 256 : 0);      // + FP4 tiles and scale dwords (k_gconv_mfma, WS = 2)
+    return ((npix + 7) / 8) * 1024 * (xs ? 2 : 1) + (mx ? 4 * n64 * 1024 + 2 * n64 * 256 : 0);      // + the lo plane's tile (XS) / + FP4 tiles and scale dwords (WS = 2)
 }
 
 static int device_cus() {
@@ -459,7 +489,7 @@ static int device_cus() {
 // few tiles per workgroup lose less to the last, partly filled round and to the rows past the image with the lower tile
 // (measured at 1080p: layer4 88 -> 83 us, layer2 32 -> 30 us with 4 rows; layer1 ties and keeps 8).
 static int gconv_pick_th(const avl_seg_op& op, int comb, int cus, int* nsp_out, int* nslots_out) {
-    const bool mx = op.w_split == 2;
+    const bool mx = op.w_split == 2, xs = op.in_lo != nullptr;
     const int d = comb ? 1 : op.dil;
     const int gh = comb ? (op.out_h + op.dil - 1) / op.dil : op.out_h, gw = comb ? (op.out_w + op.dil - 1) / op.dil : op.out_w;
     const int ncomb = comb ? op.dil * op.dil : 1, cchunks = op.in_c / CC;
@@ -467,8 +497,8 @@ static int gconv_pick_th(const avl_seg_op& op, int comb, int cus, int* nsp_out, 
     double best_cost = 0.;
     const int env_th = AVL_EXP_INT("AVL_GCONV_TH", 0);      // experiments build only
     for (int th = 8; th >= 2; th >>= 1) {
-        if (2 * gconv_tile_bytes(op.stride, d, th, mx) > 160 * 1024) continue;
-        if (mx && th == 8) continue;                 // the MX variant with four sub-tiles per wave spills
+        if (2 * gconv_tile_bytes(op.stride, d, th, mx, xs) > 160 * 1024) continue;
+        if ((mx || xs) && th == 8) continue;         // the MX variant with four sub-tiles per wave spills; the split-input one has no LDS for it
         const int nsp = ((gw + TW - 1) / TW) * ((gh + th - 1) / th) * ncomb;
         int nslots = cus / cchunks;
         if (nslots < 1) nslots = 1;
@@ -484,10 +514,11 @@ static int gconv_pick_th(const avl_seg_op& op, int comb, int cus, int* nsp_out, 
     return best;
 }
 
-template <typename HT, int WS>
+template <typename HT, int WS, bool XS = false>
 int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
     GconvArgs<HT> a;
     a.in = static_cast<const HT*>(op.in);
+    a.in_lo = static_cast<const HT*>(op.in_lo);
     a.w = static_cast<const HT*>(op.weight);
     a.bias = op.bias;
     a.out = static_cast<HT*>(op.out);
@@ -505,7 +536,7 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
     a.comb = (op.stride == 1 && op.dil > 1 && op.pad == op.dil) ? 1 : 0;
     a.th = gconv_pick_th(op, a.comb, device_cus(), &a.nsp, &a.nslots);
     AVL_REQUIRE(a.th > 0, "grouped conv: no tile height fits two LDS buffers");
-    a.tile_bytes = gconv_tile_bytes(op.stride, a.comb ? 1 : op.dil, a.th, WS == 2);
+    a.tile_bytes = gconv_tile_bytes(op.stride, a.comb ? 1 : op.dil, a.th, WS == 2, XS);
     a.w4 = a.w4s = a.xq[0] = a.xq[1] = a.xs[0] = a.xs[1] = nullptr;
     a.x_srows = op.in_rows;
     if (WS == 2) {
@@ -530,8 +561,8 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
     a.cchunks = op.in_c / CC;
 #define AVL_GCONV_LAUNCH(NJ)                                                                                                          \
     do {                                                                                                                              \
-        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv_mfma<HT, WS, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((k_gconv_mfma<HT, WS, NJ>), dim3(a.nslots * a.cchunks), dim3(512), 2 * a.tile_bytes, s, a);             \
+        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv_mfma<HT, WS, NJ, XS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((k_gconv_mfma<HT, WS, NJ, XS>), dim3(a.nslots * a.cchunks), dim3(512), 2 * a.tile_bytes, s, a);             \
     } while (0)
     a.dephase = AVL_EXP_INT("AVL_GC_DEPHASE", 1);
     a.dbg = nullptr;
@@ -549,8 +580,8 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
 #endif
     // (the MX variant never runs four sub-tiles per wave -- gconv_pick_th: it would spill -- so that kernel is not even instantiated)
     if (a.th == 8) {
-        if constexpr (WS != 2) AVL_GCONV_LAUNCH(4);
-        else return avl::set_error(AVL_E_ARG, "MX grouped conv: tile height 8 is not built");
+        if constexpr (WS != 2 && !XS) AVL_GCONV_LAUNCH(4);
+        else return avl::set_error(AVL_E_ARG, "MX / split-input grouped conv: tile height 8 is not built");
     }
     else if (a.th == 4) AVL_GCONV_LAUNCH(2);
     else AVL_GCONV_LAUNCH(1);
@@ -572,6 +603,7 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
 
 int launch_gconv_mfma(const avl_seg_op& op, hipStream_t s) {
     if (op.w_split == 2) return launch_gconv_typed<f16, 2>(op, s);
+    if (op.w_split && op.in_lo) return launch_gconv_typed<f16, 1, true>(op, s);
     if (op.w_split) return launch_gconv_typed<f16, 1>(op, s);
     return op.dtype == AVL_F16 ? launch_gconv_typed<f16, 0>(op, s) : launch_gconv_typed<bf16, 0>(op, s);
 }
@@ -580,7 +612,8 @@ int validate_gconv_mfma(const avl_seg_op& op) {
     AVL_REQUIRE(is_half(op.dtype), "MFMA grouped conv needs a 16-bit activation type");
     AVL_REQUIRE(op.in_c % CC == 0, "MFMA grouped conv needs channels %% 64 == 0 (got %d)", op.in_c);
     AVL_REQUIRE(!op.w_split || op.dtype == AVL_F16, "split weights need AVL_F16 activations");
-    AVL_REQUIRE(!op.in_lo && !op.in2_lo && (!op.out_lo || op.w_split), "grouped conv: only the output may be split, and only with w_split");
+    AVL_REQUIRE(!op.in2_lo && (!op.out_lo || op.w_split) && (!op.in_lo || op.w_split == 1), "grouped conv: a split output needs w_split, a split input w_split = 1");
+    AVL_REQUIRE(!op.in_lo || reinterpret_cast<uintptr_t>(op.in_lo) % 16 == 0, "grouped conv: unaligned lo plane");
     if (op.w_split == 2) {
         AVL_REQUIRE(op.w_mx && op.in_mx && op.in_c % 256 == 0 && op.in_ld == op.in_c, "MX grouped conv: w_mx, in_mx, channels %% 256 == 0, dense input rows");
         AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.w_mx) | reinterpret_cast<uintptr_t>(op.in_mx)) % 16 == 0, "MX grouped conv: unaligned bundles");
@@ -594,7 +627,7 @@ int validate_gconv_mfma(const avl_seg_op& op) {
                 "grouped conv: output planes beyond 2 GB (32-bit epilogue addressing)");
     const int cg = op.in_c / op.groups;
     AVL_REQUIRE(cg <= 32 && 32 % cg == 0, "MFMA grouped conv needs <= 32 channels per group dividing 32 (got %d)", cg);
-    AVL_REQUIRE(2 * gconv_tile_bytes(op.stride, (op.stride == 1 && op.pad == op.dil) ? 1 : op.dil, 2) <= 160 * 1024, "grouped conv: two tile buffers do not fit LDS (dilation %d)", op.dil);
+    AVL_REQUIRE(2 * gconv_tile_bytes(op.stride, (op.stride == 1 && op.pad == op.dil) ? 1 : op.dil, 2, false, op.in_lo != nullptr) <= 160 * 1024, "grouped conv: two tile buffers do not fit LDS (dilation %d)", op.dil);
     return AVL_OK;
 }
 

@@ -26,19 +26,24 @@ constexpr int ROW = 224;                                      // bf16 values per
 template <typename HT>
 struct StemArgs {
     const unsigned char* img;
-    const HT* w;           // [nj 4][step 6][i 16][k 32]
+    const HT* w;           // [nj 4][step 6][i 16][k 32]; SPLIT: the hi parts, then the same array of lo parts
     const float* bias;    // [64]
     HT* out;
+    HT* out_lo;            // SPLIT: the result's lo plane
     int H, W, OH, OW, out_ld, tiles_x;
     const PreCamera* cam;      // PRE: device memory (one captured graph serves both cameras)
     int srcH, srcW, factor;    // PRE: the raw frame; H = srcH / factor, W = srcW / factor
 };
 
-template <typename HT, bool PRE>
+// SPLIT (the complete hi + lo pipeline): the NORMALISED image is kept as two f16 tiles (value = hi + lo), the weights are
+// f16 pairs, the product runs Wh.xh + Wl.xh + Wh.xl and the result leaves as hi + lo planes: no f16-class rounding anywhere.
+template <typename HT, bool PRE, bool SPLIT = false>
 __global__ void __launch_bounds__(256) k_stem_mfma(StemArgs<HT> p) {
     typedef typename Half16<HT>::v8 v8;
     __shared__ __attribute__((aligned(16))) HT tile[(IN_TH + 1) * ROW];
+    __shared__ __attribute__((aligned(16))) HT tile_lo[SPLIT ? (IN_TH + 1) * ROW : 8];
     __shared__ HT lut[3 * 256];        // normalised value of every (channel, byte): exact divisions, done once
+    __shared__ HT lut_lo[SPLIT ? 3 * 256 : 8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
@@ -47,11 +52,15 @@ __global__ void __launch_bounds__(256) k_stem_mfma(StemArgs<HT> p) {
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     if constexpr (PRE) {
 #pragma unroll
-        for (int ci = 0; ci < 3; ++ci) lut[ci * 256 + tid] = (HT)(((float)tid / 255.0f - mean[ci]) / stdv[ci]);
+        for (int ci = 0; ci < 3; ++ci) {
+            const float v = ((float)tid / 255.0f - mean[ci]) / stdv[ci];
+            lut[ci * 256 + tid] = (HT)v;
+            if constexpr (SPLIT) lut_lo[ci * 256 + tid] = (HT)(v - (float)(HT)v);
+        }
         // the slack of every row and the extra row (read by the zero-weight pad taps)
         for (int e = tid; e < (IN_TH + 1) * ROW; e += 256) {
             const int ly = e / ROW, lc = e - ly * ROW;
-            if (ly >= IN_TH || lc >= IN_TW * 3) tile[e] = (HT)0.f;
+            if (ly >= IN_TH || lc >= IN_TW * 3) { tile[e] = (HT)0.f; if constexpr (SPLIT) tile_lo[e] = (HT)0.f; }
         }
         const PreCamera cam = *p.cam;
         __syncthreads();
@@ -64,6 +73,11 @@ __global__ void __launch_bounds__(256) k_stem_mfma(StemArgs<HT> p) {
             HT* t = tile + ly * ROW + lx * 3;
 #pragma unroll
             for (int c = 0; c < 3; ++c) t[c] = ok ? lut[c * 256 + rgb[c]] : (HT)0.f;
+            if constexpr (SPLIT) {
+                HT* tl = tile_lo + ly * ROW + lx * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tl[c] = ok ? lut_lo[c * 256 + rgb[c]] : (HT)0.f;
+            }
         }
     } else {
         // all of a lane's byte loads are issued before the first conversion (the element-at-a-time loop was a chain of
@@ -84,7 +98,11 @@ __global__ void __launch_bounds__(256) k_stem_mfma(StemArgs<HT> p) {
         }
         // while the loads are in flight: the 768-entry table
     #pragma unroll
-        for (int ci = 0; ci < 3; ++ci) lut[ci * 256 + tid] = (HT)(((float)tid / 255.0f - mean[ci]) / stdv[ci]);
+        for (int ci = 0; ci < 3; ++ci) {
+            const float v = ((float)tid / 255.0f - mean[ci]) / stdv[ci];
+            lut[ci * 256 + tid] = (HT)v;
+            if constexpr (SPLIT) lut_lo[ci * 256 + tid] = (HT)(v - (float)(HT)v);
+        }
         __syncthreads();
     #pragma unroll
         for (int i = 0; i < NE; ++i) {
@@ -92,6 +110,7 @@ __global__ void __launch_bounds__(256) k_stem_mfma(StemArgs<HT> p) {
             if (e < (IN_TH + 1) * ROW) {
                 const int ci = (e % ROW) % 3;
                 tile[e] = ((okmask >> i) & 1u) ? lut[ci * 256 + px[i]] : (HT)0.f;
+                if constexpr (SPLIT) tile_lo[e] = ((okmask >> i) & 1u) ? lut_lo[ci * 256 + px[i]] : (HT)0.f;
             }
         }
     }
@@ -131,6 +150,24 @@ __global__ void __launch_bounds__(256) k_stem_mfma(StemArgs<HT> p) {
             }
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) acc[nj] = Half16<HT>::mfma(wf[nj][st], a, acc[nj]);
+            if constexpr (SPLIT) {
+                v8 al;
+                if (q < 21) {
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(tile_lo + (sy * 2 + ky) * ROW + sx * 6 + piece * 8);
+                    uint32_t u[4] = {src[0], src[1], src[2], src[3]};
+                    __builtin_memcpy(&al, u, 16);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) al[i] = (HT)0.f;
+                }
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) {
+                    // the lo parts of the weights are not kept in registers (96 more): 24 L1-resident 16-byte loads per sub-tile
+                    const v8 wl = *reinterpret_cast<const v8*>(p.w + 4 * 6 * 16 * 32 + ((nj * 6 + st) * 16 + fr) * 32 + kq * 8);
+                    acc[nj] = Half16<HT>::mfma(wf[nj][st], al, acc[nj]);
+                    acc[nj] = Half16<HT>::mfma(wl, a, acc[nj]);
+                }
+            }
         }
         const int oy = oy0 + sy, ox = ox0 + sx;
         if (oy < p.OH && ox < p.OW) {
@@ -143,6 +180,18 @@ __global__ void __launch_bounds__(256) k_stem_mfma(StemArgs<HT> p) {
                 hi[4 + r] = fmaxf(acc[3][r] + bias[12 + r], 0.f);
             }
             HT* op = p.out + ((long long)oy * p.OW + ox) * p.out_ld + kq * 16;
+            if constexpr (SPLIT) {
+                float l0[8], l1[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float h0 = (float)(HT)lo[r], h1 = (float)(HT)hi[r];
+                    l0[r] = lo[r] - h0; l1[r] = hi[r] - h1;
+                    lo[r] = h0; hi[r] = h1;
+                }
+                HT* ol = p.out_lo + ((long long)oy * p.OW + ox) * p.out_ld + kq * 16;
+                Vec8<HT>::store(ol, l0);
+                Vec8<HT>::store(ol + 8, l1);
+            }
             Vec8<HT>::store(op, lo);
             Vec8<HT>::store(op + 8, hi);
         }
@@ -158,6 +207,7 @@ int launch_stem_typed(const avl_seg_op& op, hipStream_t s) {
     a.w = static_cast<const HT*>(op.weight);
     a.bias = op.bias;
     a.out = static_cast<HT*>(op.out);
+    a.out_lo = static_cast<HT*>(op.out_lo);
     a.H = op.in_h; a.W = op.in_w; a.OH = op.out_h; a.OW = op.out_w; a.out_ld = op.out_ld;
     a.tiles_x = (op.out_w + S_TW - 1) / S_TW;
     const int tiles_y = (op.out_h + S_TH - 1) / S_TH;
@@ -165,7 +215,13 @@ int launch_stem_typed(const avl_seg_op& op, hipStream_t s) {
     a.srcW = op.in2_ld;
     a.srcH = op.in2_ld > 0 ? op.in_rows / op.in2_ld : 0;
     a.factor = op.in_w > 0 ? a.srcW / op.in_w : 1;
-    if (op.in2)
+    if (op.w_split) {
+        if (!op.out_lo) return set_error(AVL_E_ARG, "split stem (w_split = 1): out_lo is NULL");
+        if (op.in2)
+            hipLaunchKernelGGL((k_stem_mfma<HT, true, true>), dim3(a.tiles_x * tiles_y), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((k_stem_mfma<HT, false, true>), dim3(a.tiles_x * tiles_y), dim3(256), 0, s, a);
+    } else if (op.in2)
         hipLaunchKernelGGL((k_stem_mfma<HT, true>), dim3(a.tiles_x * tiles_y), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((k_stem_mfma<HT, false>), dim3(a.tiles_x * tiles_y), dim3(256), 0, s, a);

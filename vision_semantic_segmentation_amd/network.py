@@ -500,7 +500,7 @@ class SegNet(object):
     native plan.  ``forward(image_u8_cuda)`` runs it; ``labels`` / ``logits`` are views of its outputs."""
 
     ROW_PAD = 256        # GEMM tiles read whole 128/256-row tiles
-    MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx", "dw_exact", "layer1_lo", "fuse_block")    # keyword switches of the "mixed" mode
+    MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx", "dw_exact", "layer1_lo", "fuse_block", "full_split")    # keyword switches of the "mixed" mode
 
     def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8, fuse_dwpw=True, raw_frame=None,
                  part=None, **mixed_opts):
@@ -538,11 +538,20 @@ class SegNet(object):
         # fuse_block (default): every Bottleneck of layer1 is ONE kernel (AVL_OP_BOTTLENECK: conv1 -> grouped 3x3 -> conv3 + residual with
         # both intermediates in LDS); False = the three-launch form of rounds 1-4
         self.mixed_fuse_block = self.mixed and mixed_opts.get("fuse_block", True)
-        self.mixed_gconv_mx = mixed_opts.get("gconv_mx", True)   # grouped conv with FP4 corrections for its weights AND for conv1's output (-10..-30 % logits error, -5 % frames/s)
+        # full_split: the COMPLETE hi + lo pipeline -- every tensor two f16 planes (stem output, max-pool, conv1 outputs and the
+        # ASPP depthwise stage included), every product three f16 passes, no FP4 anywhere: the plan a calibrated (trained) checkpoint needs
+        # for 1e-3, about 3x the fp32 plan's speed.  It overrides the options it contradicts.
+        self.full_split = self.mixed and bool(mixed_opts.get("full_split", False))
+        if self.full_split:
+            self.mixed_mx = False
+            self.mixed_trunk_fp4 = False
+            self.mixed_layer1_lo = True
+            self.mixed_fuse_block = False        # (the fused layer1 block has no LDS for a t1 lo plane at 256 input channels)
+        self.mixed_gconv_mx = mixed_opts.get("gconv_mx", True) and not self.full_split   # grouped conv with FP4 corrections for its weights AND for conv1's output (-10..-30 % logits error, -5 % frames/s)
         self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "mixed": torch.float16}[precision]
         self.avl_dtype = {"bf16": _lib.AVL_BF16, "f16": _lib.AVL_F16, "f32": _lib.AVL_F32, "mixed": _lib.AVL_F16}[precision]
         self.half = precision != "f32"              # 16-bit activations: MFMA stem / grouped-conv kernels
-        self.fuse_dwpw = bool(fuse_dwpw)            # ASPP branches: depthwise + pointwise as one kernel (16-bit types)
+        self.fuse_dwpw = bool(fuse_dwpw) and not self.full_split   # ASPP branches: depthwise + pointwise as one kernel (16-bit types); full_split: two kernels (split in, split out; three passes)
         self.num_classes = num_classes
         self._keep = []            # every tensor the plan points at
         self._free = {}            # numel -> [tensor] pool of released activation buffers
@@ -769,19 +778,24 @@ class SegNet(object):
         # ---- stem: conv1 7x7 s2 + bn1 + relu (resnet.py:25-27), maxpool (:28)
         h2, w2 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         w, b = fold_bn(st, "backbone.conv1.weight", "backbone.bn1")
-        if self.half:
+        if self.full_split:         # f16 pairs: the hi parts' fragments, then the lo parts'
+            whi, wlo = split_f16(w)
+            w_stem, stem_layout = self._dev(torch.cat([pack_stem_mfma(whi.to(torch.float64)), pack_stem_mfma(wlo.to(torch.float64))]), torch.float16), 1
+        elif self.half:
             w_stem, stem_layout = self._dev(pack_stem_mfma(w), self.act_dtype), 1
         else:
             w_stem, stem_layout = self._dev(w.permute(2, 3, 1, 0).reshape(-1), torch.float32), 0   # [ky][kx][ci][co]
         b_stem = self._dev(b, torch.float32)
-        stem = self._act(h2 * w2, 64)
+        stem = self._act(h2 * w2, 64, split=self.full_split)
         raw = {} if self.raw_frame is None else dict(in2=self.camera_block.data_ptr(), in2_ld=self.raw_frame[1])
         self._op("backbone.conv1", OP_STEM, in_=self.image.data_ptr(), out=stem.hi.data_ptr(), weight=w_stem.data_ptr(),
                  bias=b_stem.data_ptr(), in_h=H, in_w=W, in_c=3, in_ld=3, in_rows=self.image.shape[0] * self.image.shape[1], out_h=h2, out_w=w2,
-                 out_c=64, out_ld=64, out_rows=stem.shape[0], ksize=7, stride=2, pad=3, dil=1, groups=1, relu=1, w_layout=stem_layout, **raw)
+                 out_c=64, out_ld=64, out_rows=stem.shape[0], ksize=7, stride=2, pad=3, dil=1, groups=1, relu=1, w_layout=stem_layout,
+                 w_split=int(self.full_split), out_lo=self._lo(stem), **raw)
         h4, w4 = (h2 + 2 - 3) // 2 + 1, (w2 + 2 - 3) // 2 + 1
-        x = self._act(h4 * w4, 64)
-        self._spatial("backbone.maxpool", OP_MAXPOOL, stem, (h2, w2), 64, x, (h4, w4), 64, ksize=3, stride=2, pad=1, dil=1)
+        x = self._act(h4 * w4, 64, split=self.full_split)
+        self._spatial("backbone.maxpool", OP_MAXPOOL, stem, (h2, w2), 64, x, (h4, w4), 64, ksize=3, stride=2, pad=1, dil=1,
+                      **(dict(in_lo=self._lo(stem), out_lo=self._lo(x)) if self.full_split else {}))
         self._release(stem)
 
         # ---- layer1..4 (torchvision _make_layer, replace_stride_with_dilation = (False, True, True))
@@ -816,7 +830,7 @@ class SegNet(object):
                 # then corrects for the rounding of conv1's output too -- the largest single error term otherwise
                 conv1_mx = (self.mixed_mx and self.mixed_gconv_mx and x.mx is not None and x.mx_valid and x.hi.shape[1] == cin
                             and cin % 256 == 0 and width % 256 == 0 and 32 % (width // GROUPS) == 0)
-                t1 = self._act(hw[0] * hw[1], width, mx=conv1_mx, lo_fp4=conv1_mx)
+                t1 = self._act(hw[0] * hw[1], width, split=self.full_split, mx=conv1_mx, lo_fp4=conv1_mx)
                 self._gemm(p + ".conv1", x, hw, cin, w, b, t1, read_lo=self.mixed_conv1_split)
                 # conv2 3x3 grouped + bn2 + relu
                 w, b = fold_bn(st, p + ".conv2.weight", p + ".bn2")
@@ -846,8 +860,21 @@ class SegNet(object):
                 # (conv3 as an MX GEMM reads the 3x3 output's lo part only through its FP4 copy: no f16 lo plane then)
                 t2_fp4 = self.mixed_conv2_split and self.mixed_trunk_fp4 and width % 256 == 0 and cout % 256 == 0 and layout == 1
                 t2 = self._act(ohw[0] * ohw[1], width, split=self.mixed_conv2_split, mx=True, lo_fp4=t2_fp4)
-                self._spatial(p + ".conv2", OP_GCONV, t1, hw, width, t2, ohw, width, wg_d, bg_d, ksize=3, stride=s, pad=d, dil=d,
-                              groups=GROUPS, relu=1, w_layout=layout, w_split=wsplit, **extra_g)
+                if self.full_split:
+                    assert layout == 1 and wsplit == 1 and t1.lo is not None, "full_split needs the MFMA grouped conv with split weights"
+                    extra_g = dict(in_lo=self._lo(t1))
+                if self.full_split and s != 1:
+                    # two tile buffers of a stride-2 tile do not fit the LDS with a lo plane beside the hi plane: the one strided 3x3 of the
+                    # network (layer2.0) runs at stride 1 and its result is sub-sampled (pad 1: out(y, x) = out1(2 y, 2 x))
+                    t2f = self._act(hw[0] * hw[1], width, split=True)
+                    self._spatial(p + ".conv2", OP_GCONV, t1, hw, width, t2f, hw, width, wg_d, bg_d, ksize=3, stride=1, pad=d, dil=d,
+                                  groups=GROUPS, relu=1, w_layout=layout, w_split=wsplit, **extra_g)
+                    self._spatial(p + ".conv2.sub", OP_SUBSAMPLE, t2f, hw, width, t2, ohw, width, stride=s)
+                    self._spatial(p + ".conv2.sub[lo]", OP_SUBSAMPLE, t2f.lo, hw, width, t2.lo, ohw, width, stride=s)
+                    self._release(t2f)
+                else:
+                    self._spatial(p + ".conv2", OP_GCONV, t1, hw, width, t2, ohw, width, wg_d, bg_d, ksize=3, stride=s, pad=d, dil=d,
+                                  groups=GROUPS, relu=1, w_layout=layout, w_split=wsplit, **extra_g)
                 self._release(t1)
                 # identity / downsample.  Stride-1 downsamples (layer3.0, layer4.0) whose input and the 3x3 output both carry MX
                 # bundles are folded into conv3 as a second input along K: the identity tensor never exists
@@ -1094,6 +1121,35 @@ class SegNet(object):
         s = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(_lib.lib().avl_seg_plan_profile(self._plan, C.c_void_p(s), ms, fl, by), "avl_seg_plan_profile")
         return [dict(name=self.op_names[i], kind=OP_NAMES[self.ops[i].kind], ms=ms[i], flops=fl[i], bytes=by[i]) for i in range(n)]
+
+    def op_output(self, i):
+        """float32 CPU tensor [out_h * out_w, out_c] of what op i wrote (hi + lo planes) -- valid right after a run of ops 0 .. i only (later ops
+        recycle the buffers): diagnostics and tests (tools/layer_error_trace.py)."""
+        op = self.ops[i]
+        rows, cols = op.out_h * op.out_w, op.out_c
+        dt = torch.float32 if (op.out_f32 or op.dtype == _lib.AVL_F32) else self.act_dtype
+
+        def plane(ptr):
+            for t in self._keep + ([self.logits_buf] if hasattr(self, "logits_buf") else []):
+                lo, hi = t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()
+                if lo <= ptr < hi:
+                    flat = t.reshape(-1).view(torch.uint8)[ptr - lo:].view(dt)
+                    return torch.as_strided(flat, (rows, cols), (op.out_ld, 1)).float().cpu()
+            raise KeyError("op %d: output pointer not in the plan's buffers" % i)
+        y = plane(op.out)
+        return y + plane(op.out_lo) if op.out_lo else y
+
+    def run_prefix(self, n_ops, stream=None):
+        """ops 0 .. n_ops - 1 only (a plan of their own): diagnostics and tests"""
+        plan = C.c_void_p()
+        arr = (AvlSegOp * n_ops)(*self.ops[:n_ops])
+        _lib.check(_lib.lib().avl_seg_plan_create(arr, n_ops, C.byref(plan)), "avl_seg_plan_create")
+        try:
+            s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+            _lib.check(_lib.lib().avl_seg_plan_run(plan, C.c_void_p(s)), "avl_seg_plan_run")
+            torch.cuda.synchronize(self.device)
+        finally:
+            _lib.lib().avl_seg_plan_destroy(plan)
 
     def nonfinite_counts(self):
         """Runs the plan's ops one by one (never the captured graph) and counts Inf / NaN values in every op's output where it is

@@ -57,7 +57,8 @@ class SemanticSegmentation(object):
         # produced.  The check walks a LADDER of plans and keeps the first one that passes:
         #   "mixed"       as configured (f16 + FP4 matrix cores)
         #   "mixed+lo"    + MIXED_LAYER1_LO (every layer1 block keeps its lo plane)
-        #   "split16"     every correction product as an f16 pass on f16 hi + lo planes, no FP4 anywhere (round 2's 173 frames/s form)
+        #   "split16"     the COMPLETE hi + lo pipeline (SegNet(full_split=True)): every tensor two f16 planes, every product three f16 passes, no
+        #                 FP4 and no single-plane tensor anywhere -- what a calibrated (trained) checkpoint needs
         #   "f32"         fp32-input MFMA, the reference's precision (50 frames/s)
         sc = getattr(cfg.MODEL, "MIXED_SELF_CHECK", "auto")
         self._self_check = (state_dict is None and bool(cfg.MODEL.WEIGHT)) if sc == "auto" else _strict_bool(sc, "MODEL.MIXED_SELF_CHECK")
@@ -93,7 +94,7 @@ class SemanticSegmentation(object):
         if rung in ("f32", "f16", "bf16"):
             return SegNet(self.state, h, w, precision=rung, **kw)
         if rung == "split16":
-            return SegNet(self.state, h, w, precision="mixed", mx=False, gconv_mx=False, trunk_fp4=False, layer1_lo=True, **kw)
+            return SegNet(self.state, h, w, precision="mixed", full_split=True, **kw)
         return SegNet(self.state, h, w, precision="mixed",
                       conv2_split=bool(getattr(self.cfg.MODEL, "MIXED_CONV2_SPLIT", True)),
                       gconv_mx=bool(getattr(self.cfg.MODEL, "MIXED_GCONV_MX", True)),
