@@ -1,6 +1,6 @@
 set -e
 export TMPDIR=/tmp
-mkdir -p gpurun_out/final gpurun_out/r4
+mkdir -p gpurun_out/final gpurun_out/r5
 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
 bash tools/prof_bench.sh > gpurun_out/final/prof_bench.out 2>&1
 bash tools/pmc_seg.sh mixed > gpurun_out/final/pmc_seg.out 2>&1
