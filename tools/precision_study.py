@@ -112,7 +112,11 @@ def forward(st, image_u8, pol):
             xh = rnd(x, "f16")
             xl = x - xh
             y = F.conv2d(xh, wh, b.to(torch.float32), **kw)
-            y = y + F.conv2d(mx_quant(xh, 1, fmt), mx_quant(wl, 1, fmt), None, **kw)
+            # PS_SKIP_WL = comma-separated stage prefixes whose Q(W lo) . Q(x hi) term is dropped (is the FP4 copy of a
+            # trunk tensor's HI part worth its bytes?)
+            skip_wl = any(stage.startswith(pre) for pre in os.environ.get("PS_SKIP_WL", "").split(",") if pre)
+            if not skip_wl:
+                y = y + F.conv2d(mx_quant(xh, 1, fmt), mx_quant(wl, 1, fmt), None, **kw)
             if float(xl.abs().max()) > 0:
                 y = y + F.conv2d(mx_quant(xl, 1, fmt), mx_quant(wh, 1, fmt), None, **kw)
         else:
@@ -318,6 +322,24 @@ def main():
         report("  + aspp dw all exact", Policy("f16", **e3))
         report("  + aspp dw all exact + stem w split + stem out exact", Policy("f16", **dict(e3, **{"stem:w": X, "stem:a": "f32"})))
         report("  + aspp dw out split only (weights f16)", Policy("f16", **dict(d, **{"aspp.b1.dw:a": "f32", "aspp.b2.dw:a": "f32", "aspp.b3.dw:a": "f32"})))
+    if sel == "wl":
+        # the built configuration (gconv_mx, trunk f16 + FP4 lo) with the weights' lo correction dropped for the conv1s of a layer
+        def blocks(which, conv, dd):
+            for li, b in which:
+                dd["layer%d.%d.%s:a" % (li, b, conv)] = "f32"
+            return dd
+        ALL = [(li, b) for li, nb in ((1, 3), (2, 4), (3, 6), (4, 3)) for b in range(nb)]
+        MXB = [(li, b) for (li, b) in ALL if li >= 3 or (li == 2 and b >= 1)]
+        d = {":w": "mx4", ":t": "f16q4", ":ta": "f32", "stem": "f16", "dec": "f32", "dec:w": "mx4", "aspp.b0:a": "f32", "aspp.proj:a": "f32"}
+        for i in (1, 2, 3):
+            d["aspp.b%d.dw:w" % i] = "f32"
+            d["aspp.b%d.dw:a" % i] = "f32"
+            d["aspp.b%d.pw:a" % i] = "f32"
+        g = blocks(MXB, "conv1", blocks(ALL, "conv2", d))
+        for skip in ("", "layer4.1.conv1,layer4.2.conv1", "layer4.0.conv1,layer4.1.conv1,layer4.2.conv1", "layer3", "layer4", "layer3,layer4"):
+            os.environ["PS_SKIP_WL"] = skip
+            report("built config; W lo term dropped in: %s" % (skip or "-"), Policy("f16", **g))
+        os.environ["PS_SKIP_WL"] = ""
     if sel == "heavy":
         # round 5: which roundings does a CALIBRATED network (every BN subtracts the mean of what it normalises) not forgive?
         def blocks(which, conv, dd, kind="f32"):
