@@ -24,6 +24,10 @@
 
 #include "seg_types.h"
 
+#ifndef BN_EXP
+#define BN_EXP 0          // hook for same-box A/B builds of tuning variants (tools/ab_bottleneck.sh: make EXPFLAGS=-DBN_EXP=n OUT=... BUILD=...); 0 = what ships
+#endif
+
 namespace avl {
 namespace {
 
@@ -163,7 +167,9 @@ __global__ void __launch_bounds__(512) k_bottleneck(BnArgs p) {
         return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, wlane, frag * 1024, 0));
     };
     const int ch0 = 32 * wave + 8 * q;                     // conv3: this lane's 8 output channels
-    // conv1's weights stay in registers for the whole tile (row tiles outside, K steps inside); requested at the top of the tile
+    // conv1's weights stay in registers for the whole tile (row tiles outside, K steps inside); requested at the top of the tile.
+    // (Requesting the NEXT tile's during conv3, so that their L2 round trip is not exposed at the top of the tile, was measured: -1 us on
+    // the single-plane variant, +8 us with a split output -- the 64 registers are missed in conv3 -- and spills with a split residual.)
     f16x8 w1f[KS1][2];
 
     for (; tile < p.ntiles; tile += gridDim.x, ++it) {
@@ -229,6 +235,7 @@ __global__ void __launch_bounds__(512) k_bottleneck(BnArgs p) {
                 th[ks] = *reinterpret_cast<const f16x8*>(A + off);
                 if constexpr (T1LO) tl[ks] = *reinterpret_cast<const f16x8*>(A + L::T1LO_OFF + off);
             }
+            __builtin_amdgcn_sched_barrier(0);      // all of the row's fragments are requested before its first MFMA (hipcc otherwise pairs them up: one LDS round trip per two MFMAs; same-box A/B: -1.5 .. -4 us per block)
 #pragma unroll
             for (int ks = 0; ks < 5; ++ks) {
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[ks][0], th[ks], acc, 0, 0, 0);
@@ -243,6 +250,27 @@ __global__ void __launch_bounds__(512) k_bottleneck(BnArgs p) {
             *reinterpret_cast<uint2*>(A + a_wr + r * 4096) = hi;
             if constexpr (T1LO) *reinterpret_cast<uint2*>(A + L::T2LO_OFF + a_wr + r * 4096) = lo;
             else t2lo[r] = lo;
+        };
+        // everything conv3 needs from global memory is requested BEFORE the X DMA of the next tile goes out (vmcnt counts in issue order: a load
+        // behind the DMA burst would wait for the burst's HBM round trip at its first use) -- and as early as registers allow
+        f16x8 w3f[KS3][4];
+        uint4 resh[DS ? 1 : BT_H], resl[XLO ? BT_H : 1];
+        static_assert(!(DS && XLO), "the downsample variant has no identity residual");
+        auto preload_conv3 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < KS3; ++ks)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) w3f[ks][f] = wfrag(w3r, ks * 4 + f);
+            if constexpr (!DS) {
+                // identity: the block input at the tile's own pixels, in accumulator layout (16 B per lane; L2 / MALL hits: the tile was staged from there)
+#pragma unroll
+                for (int rr = 0; rr < BT_H; ++rr) {
+                    const int oy = min(ty * BT_H + rr, p.H - 1), ox = min(tx * BT_W + co, p.W - 1);
+                    const unsigned roff = (unsigned)(oy * p.W + ox) * (unsigned)p.in_ld + (unsigned)ch0;
+                    resh[rr] = *reinterpret_cast<const uint4*>(p.x + roff);
+                    if constexpr (XLO) resl[rr] = *reinterpret_cast<const uint4*>(p.x_lo + roff);
+                }
+            }
         };
         {
             // X fragment addresses: slab pair (0,1 | 2,3) x K-step parity -> immediate offsets stay below 64 KB
@@ -275,6 +303,7 @@ __global__ void __launch_bounds__(512) k_bottleneck(BnArgs p) {
                     if (r >= next_row && (18 * r + 53) / 16 + 1 <= m) next_row = r + 1;
                 store_t1(m, acc);
             }
+            preload_conv3();                   // conv1's weight registers are free from here on: beside the last output rows of the 3x3
 #pragma unroll
             for (int r = 0; r < BT_H; ++r)
                 if (r >= next_row) conv2_row(r);
@@ -283,25 +312,6 @@ __global__ void __launch_bounds__(512) k_bottleneck(BnArgs p) {
         if constexpr (!T1LO) {
 #pragma unroll
             for (int r = 0; r < BT_H; ++r) *reinterpret_cast<uint2*>(A + L::T2LO_OFF + a_wr + r * 4096) = t2lo[r];
-        }
-        // ---- everything conv3 needs from global memory is requested BEFORE the X DMA of the next tile goes out: vmcnt counts in issue
-        // order, a load behind the DMA burst would wait for the burst's HBM round trip at its first use
-        f16x8 w3f[KS3][4];
-#pragma unroll
-        for (int ks = 0; ks < KS3; ++ks)
-#pragma unroll
-            for (int f = 0; f < 4; ++f) w3f[ks][f] = wfrag(w3r, ks * 4 + f);
-        uint4 resh[DS ? 1 : BT_H], resl[XLO ? BT_H : 1];
-        static_assert(!(DS && XLO), "the downsample variant has no identity residual");
-        if constexpr (!DS) {
-            // identity: the block input at the tile's own pixels, in accumulator layout (16 B per lane; L2 / MALL hits: the tile was staged from there)
-#pragma unroll
-            for (int rr = 0; rr < BT_H; ++rr) {
-                const int oy = min(ty * BT_H + rr, p.H - 1), ox = min(tx * BT_W + co, p.W - 1);
-                const unsigned roff = (unsigned)(oy * p.W + ox) * (unsigned)p.in_ld + (unsigned)ch0;
-                resh[rr] = *reinterpret_cast<const uint4*>(p.x + roff);
-                if constexpr (XLO) resl[rr] = *reinterpret_cast<const uint4*>(p.x_lo + roff);
-            }
         }
         stamp(1);
         stamp(2);
