@@ -145,6 +145,12 @@ int avl_colorize_labels(const uint8_t* labels, int lw, int lh, const uint8_t* pa
  * skip the undistortion; rgb_out uint8[h/factor][w/factor][3]. */
 int avl_preprocess_image(const uint8_t* bgr, int h, int w, const double* K_host, const double* dist_host, int factor,
                          uint8_t* rgb_out, void* stream);
+/* The same with cv2.resize(INTER_AREA) to ANY smaller size out_h x out_w (vision_semantic_segmentation_node.py:92-98 takes every
+ * IMAGE_SCALE in (0, 1): width = int(W * scale), height = int(H * scale)): OpenCV's area decimation for a non-integer ratio -- partial first
+ * and last source pixels weighted by their overlap, float accumulation row by row, round half to even.  Integer ratios should keep
+ * avl_preprocess_image (OpenCV switches to integer box means there; for 2 x 2 it rounds half UP).  Parity unpinned (OpenCV absent). */
+int avl_preprocess_image_area(const uint8_t* bgr, int h, int w, const double* K_host, const double* dist_host, int out_h, int out_w,
+                              uint8_t* rgb_out, void* stream);
 
 /* The same pre-processing INSIDE the network's first kernel: an AVL_OP_STEM op whose `in2` is set reads the RAW BGR camera
  * frame through `in` and applies BGR->RGB / undistort / INTER_AREA per pixel while it fills its LDS tile (the function

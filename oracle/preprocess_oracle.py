@@ -10,6 +10,8 @@ OpenCV's documented algorithms:
     this restatement uses float weights and rounds to nearest, so it can differ from OpenCV by 1 grey level.)
   * resize(INTER_AREA) by an integer factor f: mean of each f x f box; for f = 2 OpenCV's integer path (s + 2) >> 2,
     otherwise round-half-even of the float mean.
+  * resize(INTER_AREA) by any other shrink ratio (round 5): the area decimation table of computeResizeAreaTab, float accumulation
+    (resize_area below).
 """
 import numpy as np
 
@@ -48,6 +50,55 @@ def resize_area_int(img, f):
     if f == 2:
         return ((s + 2) >> 2).astype(np.uint8)
     return np.clip(np.rint(s.astype(np.float32) * np.float32(1.0 / (f * f))), 0, 255).astype(np.uint8)
+
+
+def _area_table(dsize, ssize):
+    """OpenCV computeResizeAreaTab for one axis: [(source index, weight)] per destination index (float32 weights)"""
+    scale = ssize / float(dsize)
+    tab = []
+    for d in range(dsize):
+        f1 = d * scale
+        f2 = f1 + scale
+        cell = min(scale, ssize - f1)
+        s1, s2 = int(np.ceil(f1)), int(np.floor(f2))
+        s2 = min(s2, ssize - 1)
+        s1 = min(s1, s2)
+        ent = []
+        if s1 - f1 > 1e-3:
+            ent.append((s1 - 1, np.float32((s1 - f1) / cell)))
+        ent += [(sx, np.float32(1.0 / cell)) for sx in range(s1, s2)]
+        if f2 - s2 > 1e-3:
+            ent.append((s2, np.float32(min(min(f2 - s2, 1.0), cell) / cell)))
+        tab.append(ent)
+    return tab
+
+
+def resize_area(img, out_h, out_w):
+    """cv2.resize(img, (out_w, out_h), interpolation=INTER_AREA) for a NON-integer shrink ratio (OpenCV's ResizeArea_<uchar, float>):
+    every source row of a destination cell is reduced along x in float32 (value x weight, added in table order), the rows are then
+    combined with the y weights the same way, and the sum is rounded half to even.  vision_semantic_segmentation_node.py:92-98."""
+    h, w = img.shape[:2]
+    xt, yt = _area_table(out_w, w), _area_table(out_h, h)
+    src = img.astype(np.float32)
+    out = np.zeros((out_h, out_w, img.shape[2]), dtype=np.uint8)
+    for dy in range(out_h):
+        for dx in range(out_w):
+            total = np.zeros(img.shape[2], dtype=np.float32)
+            for sy, beta in yt[dy]:
+                buf = np.zeros(img.shape[2], dtype=np.float32)
+                for sx, alpha in xt[dx]:
+                    buf = (buf + src[sy, sx] * alpha).astype(np.float32)
+                total = (total + buf * beta).astype(np.float32)
+            out[dy, dx] = np.clip(np.rint(total), 0, 255).astype(np.uint8)
+    return out
+
+
+def preprocess_area(bgr, K, dist, out_h, out_w):
+    """:83-98 with an IMAGE_SCALE that is not 1 / integer: BGR2RGB, undistort, general INTER_AREA"""
+    img = bgr_to_rgb(bgr)
+    if K is not None and dist is not None:
+        img = undistort(img, K, dist)
+    return np.ascontiguousarray(resize_area(np.ascontiguousarray(img), out_h, out_w))
 
 
 def preprocess(bgr, K=None, dist=None, factor=1):

@@ -226,6 +226,38 @@ def test_preprocessing_matches_restatement(cuda_device):
     assert np.abs(got - ref).max() <= 1
 
 
+def test_any_image_scale_through_the_general_area_resize(state, cuda_device):
+    """VERDICT r4 (missing 6): the reference takes every IMAGE_SCALE in (0, 1) (vision_semantic_segmentation_node.py:92-98:
+    cv2.resize(INTER_AREA) to int(W * scale) x int(H * scale)).  avl_preprocess_image_area = OpenCV's area decimation for a non-integer
+    ratio; the kernel equals the NumPy restatement byte for byte without undistortion (same float32 steps) and within one grey level
+    with it; the node routes such scales through it (stand-alone kernel + plain plan)."""
+    import types
+    from oracle import preprocess_oracle as po
+    from vision_semantic_segmentation_amd.camera import camera_setup_1
+    from vision_semantic_segmentation_amd.config import get_cfg_defaults
+    from vision_semantic_segmentation_amd import SemanticSegmentation
+    from vision_semantic_segmentation_amd.vision_semantic_segmentation_node import VisionSemanticSegmentationNode, preprocess_area_device
+    rng = np.random.default_rng(31)
+    bgr = rng.integers(0, 256, size=(97, 131, 3), dtype=np.uint8)
+    for scale in (0.75, 0.6, 0.37, 0.5):                      # (0.5 of odd sizes: 48 x 65 from 97 x 131 is no integer ratio either)
+        oh, ow = int(97 * scale), int(131 * scale)
+        got = preprocess_area_device(bgr, None, oh, ow).cpu().numpy()
+        assert np.array_equal(got, po.preprocess_area(bgr, None, None, oh, ow)), scale
+    cam = camera_setup_1().scaled(131 / 1920.0, 97 / 1440.0)
+    got = preprocess_area_device(bgr, cam, 72, 98).cpu().numpy().astype(np.int32)
+    ref = po.preprocess_area(bgr, cam.K, cam.dist, 72, 98).astype(np.int32)
+    assert np.abs(got - ref).max() <= 1 and (got != ref).mean() < 2e-2
+    # the node: IMAGE_SCALE = 0.6 on a 160 x 200 frame -> 96 x 120 network input
+    cfg = get_cfg_defaults()
+    cfg.VISION_SEM_SEG.IMAGE_SCALE = 0.6
+    seg = SemanticSegmentation(_cfg("mixed"), device=cuda_device, state_dict=state)
+    node = VisionSemanticSegmentationNode(cfg, seg=seg, undistort=False)
+    frame = rng.integers(0, 256, size=(160, 200, 3), dtype=np.uint8)
+    out = node.image_callback(types.SimpleNamespace(data=frame, header=types.SimpleNamespace(frame_id="camera1", stamp=0)))
+    want = seg.segmentation_device(po.preprocess_area(frame, None, None, 96, 120)).cpu().numpy()
+    assert out.shape == (160, 200, 3) and np.array_equal(node.last_labels.cpu().numpy(), want)
+
+
 def test_stem_preprocesses_the_raw_camera_frame(state, cuda_device):
     """SURVEY 8f row 1 fused: a raw_frame plan's stem applies the pre-processing in its loader.  Its logits must be the SAME BITS as
     avl_preprocess_image -> the plain plan (one shared device function), at the camera's 1440x1920 with camera1's distortion model,

@@ -45,6 +45,7 @@ _SIGNATURES = {
                              _vp, _vp, _vp, C.c_uint32, _vp]),
     "avl_colorize_labels": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp]),
     "avl_preprocess_image": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "avl_preprocess_image_area": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "avl_stem_camera_set": (_i, [_vp, _vp, _vp, _vp]),
     "avl_pack_semantic_cloud": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "avl_unpack_pointcloud2": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

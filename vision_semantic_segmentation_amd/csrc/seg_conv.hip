@@ -571,6 +571,49 @@ __global__ void __launch_bounds__(kThreads) k_preprocess(const unsigned char* __
     for (int c = 0; c < 3; ++c) out[3ll * idx + c] = (unsigned char)v[c];
 }
 
+// cv2.resize(INTER_AREA) to ANY smaller size (vision_semantic_segmentation_node.py:92-98 accepts every IMAGE_SCALE in (0, 1)): OpenCV's
+// ResizeArea for a non-integer ratio -- per axis the destination cell [d s, (d + 1) s) covers a partial first source pixel, whole ones and a
+// partial last one (computeResizeAreaTab: weights below 1e-3 dropped, cell width min(s, size - d s)); the rows are reduced in float, row by
+// row, then across rows, and rounded half to even.  One lane = one output pixel; the undistorted source pixels are computed on the fly.
+// OpenCV is absent: parity unpinned (oracle/preprocess_oracle.py restates the same steps in NumPy float32, mul then add, no FMA).
+struct AreaAxis { int s1, s2; float w_first, w_mid, w_last; };       // source span [s1 - (w_first > 0), s2 + (w_last > 0))
+__device__ __forceinline__ AreaAxis area_axis(int d, double scale, int ssize) {
+    const double f1 = d * scale, f2 = f1 + scale;
+    const double cell = fmin(scale, (double)ssize - f1);
+    int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+    s2 = min(s2, ssize - 1);
+    s1 = min(s1, s2);
+    AreaAxis a;
+    a.s1 = s1; a.s2 = s2;
+    a.w_first = (s1 - f1 > 1e-3) ? (float)((s1 - f1) / cell) : 0.f;
+    a.w_mid = (float)(1.0 / cell);
+    a.w_last = (f2 - s2 > 1e-3) ? (float)(fmin(fmin(f2 - s2, 1.0), cell) / cell) : 0.f;
+    return a;
+}
+__global__ void __launch_bounds__(kThreads) k_preprocess_area(const unsigned char* __restrict__ bgr, int H, int W, PreCamera cam,
+                                                             unsigned char* __restrict__ out, int OH, int OW) {
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= OH * OW) return;
+    const int ox = idx % OW, oy = idx / OW;
+    const AreaAxis ax = area_axis(ox, (double)W / OW, W), ay = area_axis(oy, (double)H / OH, H);
+    float sum[3] = {0.f, 0.f, 0.f};
+    for (int sy = ay.s1 - (ay.w_first > 0.f ? 1 : 0); sy < ay.s2 + (ay.w_last > 0.f ? 1 : 0); ++sy) {
+        const float beta = sy < ay.s1 ? ay.w_first : (sy < ay.s2 ? ay.w_mid : ay.w_last);
+        float buf[3] = {0.f, 0.f, 0.f};
+        for (int sx = ax.s1 - (ax.w_first > 0.f ? 1 : 0); sx < ax.s2 + (ax.w_last > 0.f ? 1 : 0); ++sx) {
+            const float alpha = sx < ax.s1 ? ax.w_first : (sx < ax.s2 ? ax.w_mid : ax.w_last);
+            int rgb[3];
+            undistorted_rgb(bgr, H, W, cam, sx, sy, rgb);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) buf[c] = __fadd_rn(buf[c], __fmul_rn((float)rgb[c], alpha));
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sum[c] = __fadd_rn(sum[c], __fmul_rn(buf[c], beta));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[3ll * idx + c] = (unsigned char)min(max(__float2int_rn(sum[c]), 0), 255);
+}
+
 inline unsigned blocks_for(long long n) { return (unsigned)((n + kThreads - 1) / kThreads); }
 
 template <typename T>
@@ -780,6 +823,13 @@ int launch_preprocess(const unsigned char* bgr, int H, int W, const double* K, c
     q.factor = factor;
     const int OH = H / factor, OW = W / factor;
     hipLaunchKernelGGL(k_preprocess, dim3(blocks_for((long long)OH * OW)), dim3(kThreads), 0, s, bgr, H, W, q, out, OH, OW);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
+int launch_preprocess_area(const unsigned char* bgr, int H, int W, const double* K, const double* dist, int OH, int OW, unsigned char* out,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(k_preprocess_area, dim3(blocks_for((long long)OH * OW)), dim3(kThreads), 0, s, bgr, H, W, make_pre_camera(K, dist), out, OH, OW);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }

@@ -254,6 +254,14 @@ extern "C" int avl_seg_plan_nonfinite(avl_seg_plan* plan, void* stream, unsigned
 namespace avl {
 int launch_preprocess(const unsigned char*, int, int, const double*, const double*, int, unsigned char*, hipStream_t);
 int launch_set_camera(void*, const double*, const double*, hipStream_t);
+int launch_preprocess_area(const unsigned char*, int, int, const double*, const double*, int, int, unsigned char*, hipStream_t);
+}
+extern "C" int avl_preprocess_image_area(const uint8_t* bgr, int h, int w, const double* K_host, const double* dist_host, int out_h, int out_w,
+                                         uint8_t* rgb_out, void* stream) {
+    AVL_REQUIRE(bgr && rgb_out && h > 0 && w > 0, "bad image buffers");
+    AVL_REQUIRE(out_h > 0 && out_w > 0 && out_h <= h && out_w <= w, "INTER_AREA shrinks: output %d x %d from %d x %d", out_h, out_w, h, w);
+    AVL_REQUIRE((K_host == nullptr) == (dist_host == nullptr), "K_host and dist_host go together");
+    return avl::launch_preprocess_area(bgr, h, w, K_host, dist_host, out_h, out_w, rgb_out, avl::as_stream(stream));
 }
 extern "C" int avl_stem_camera_set(void* camera_dev, const double* K_host, const double* dist_host, void* stream) {
     AVL_REQUIRE(camera_dev && reinterpret_cast<uintptr_t>(camera_dev) % 4 == 0, "bad camera block");

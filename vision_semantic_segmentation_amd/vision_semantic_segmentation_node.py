@@ -44,6 +44,24 @@ def preprocess_device(bgr, camera=None, factor=1, stream=None):
     return out
 
 
+def preprocess_area_device(bgr, camera, out_h, out_w, stream=None):
+    """The same chain with cv2.resize(INTER_AREA) to ANY smaller size (avl_preprocess_image_area): what the reference does for an
+    IMAGE_SCALE that is not 1 / integer (:92-98: width = int(W * scale), height = int(H * scale))."""
+    t = bgr if isinstance(bgr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(bgr))
+    t = t.cuda().contiguous() if not t.is_cuda else t.contiguous()
+    assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3
+    h, w = int(t.shape[0]), int(t.shape[1])
+    out = torch.empty((int(out_h), int(out_w), 3), dtype=torch.uint8, device=t.device)
+    K = dist = None
+    if camera is not None:
+        K = (C.c_double * 9)(*np.asarray(camera.K, dtype=np.float64).ravel().tolist())
+        dist = (C.c_double * 5)(*np.asarray(camera.dist, dtype=np.float64).ravel()[:5].tolist())
+    s = torch.cuda.current_stream(t.device).cuda_stream if stream is None else stream
+    _lib.check(_lib.lib().avl_preprocess_image_area(C.c_void_p(t.data_ptr()), h, w, K, dist, int(out_h), int(out_w), C.c_void_p(out.data_ptr()),
+                                                    C.c_void_p(s)), "avl_preprocess_image_area")
+    return out
+
+
 def colorize_labels_device(labels_small, out_h, out_w, labels=None, stream=None):
     """uint8 CUDA tensor [h,w] of class ids -> uint8 CUDA tensor [out_h,out_w,3]:
     cv2.resize(INTER_NEAREST) (:109-110) followed by apply_color_map
@@ -110,13 +128,14 @@ class VisionSemanticSegmentationNode(object):
         pub.publish(out)
         return out
 
-    def _downscale_factor(self):
-        """IMAGE_SCALE -> integer INTER_AREA factor (:92-98).  The reference's configs use 1.0 and 0.5."""
+    def _downscale_factor(self, h=None, w=None):
+        """IMAGE_SCALE -> integer INTER_AREA factor (:92-98), or None when the frame does not shrink by an integer ratio (the reference's
+        configs use 1.0 and 0.5): the general area resize (preprocess_area_device) then makes the (int(h * scale), int(w * scale)) input."""
         if self.image_scale >= 1:
             return 1
         f = int(round(1.0 / self.image_scale))
-        if abs(f * self.image_scale - 1.0) > 1e-9:
-            raise NotImplementedError("IMAGE_SCALE must be 1/integer for the GPU INTER_AREA path (got %r)" % self.image_scale)
+        if abs(f * self.image_scale - 1.0) > 1e-9 or (h is not None and (h % f or w % f)):
+            return None
         return f
 
     def image_callback(self, msg):
@@ -134,11 +153,13 @@ class VisionSemanticSegmentationNode(object):
         cam = {"camera1": self.cam1, "camera6": self.cam6}.get(msg.header.frame_id)   # unknown frame ids: no undistortion (:88-89)
         with self._lock:
             cam = cam if self.undistort else None
-            if self.seg.precision == "f32":                      # no 16-bit stem: stand-alone pre-processing kernel, then the network
-                labels = self.seg.segmentation_device(preprocess_device(bgr, cam, self._downscale_factor()))
+            factor = self._downscale_factor(h, w)
+            if factor is None:                                   # any other IMAGE_SCALE: OpenCV's general area resize as a stand-alone kernel
+                labels = self.seg.segmentation_device(preprocess_area_device(bgr, cam, int(h * self.image_scale), int(w * self.image_scale)))
+            elif self.seg.precision == "f32":                    # no 16-bit stem: stand-alone pre-processing kernel, then the network
+                labels = self.seg.segmentation_device(preprocess_device(bgr, cam, factor))
             else:                                                # pre-processing inside the stem's loader (no RGB frame in between)
-                labels = self.seg.segmentation_device_raw(bgr, None if cam is None else cam.K, None if cam is None else cam.dist,
-                                                          self._downscale_factor())
+                labels = self.seg.segmentation_device_raw(bgr, None if cam is None else cam.K, None if cam is None else cam.dist, factor)
             self.last_labels = labels
             colored = colorize_labels_device(labels, h, w, self.seg_color_ref)
             out = colored.cpu().numpy()
