@@ -507,7 +507,8 @@ class SegNet(object):
         """raw_frame = (src_h, src_w): the plan's input is the RAW BGR camera frame and the node's pre-processing
         (vision_semantic_segmentation_node.py:83-98: BGR->RGB, undistort, INTER_AREA by src_w // width) runs inside the stem's loader
         (16-bit precisions); ``set_camera`` chooses the camera model, ``forward`` takes the raw frame."""
-        assert output_stride == 8, "the reference configuration is OS8 (base_cfg.py:106)"
+        assert output_stride in (8, 16), "deeplab_v3_plus.py:30-36 / backbone/build.py:11-16 know output strides 8 (the reference configuration, base_cfg.py:106) and 16"
+        self.output_stride = int(output_stride)
         assert precision in ("bf16", "f16", "f32", "mixed")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.H, self.W = int(height), int(width)
@@ -802,7 +803,9 @@ class SegNet(object):
         hw, cin = (h4, w4), 64
         dilation = 1
         low = None
-        for li, (planes, nblocks, stride0, dilate) in enumerate(zip(PLANES, LAYERS, (1, 2, 2, 2), (False, False, True, True)), start=1):
+        # replace_stride_with_dilation (backbone/build.py:11-16): OS8 (False, True, True), OS16 (False, False, True)
+        dilated = (False, False, True, True) if self.output_stride == 8 else (False, False, False, True)
+        for li, (planes, nblocks, stride0, dilate) in enumerate(zip(PLANES, LAYERS, (1, 2, 2, 2), dilated), start=1):
             width = int(planes * (WIDTH_PER_GROUP / 64.0)) * GROUPS
             cout = planes * EXPANSION
             previous_dilation = dilation
@@ -960,7 +963,7 @@ class SegNet(object):
         """ASPP (aspp.py:79-95), dilations forced to 1,12,24,36 for OS8 (deeplab_v3_plus.py:33-34) -> (output Act, its channels)"""
         dev = self.device
         M = fhw[0] * fhw[1]
-        dil = (1, 12, 24, 36)
+        dil = (1, 12, 24, 36) if getattr(self, "output_stride", 8) == 8 else (1, 6, 12, 18)
         branches = []
         i = 0
         while ("aspp.module_pyramid.%d.conv.weight" % i) in st or ("aspp.module_pyramid.%d.depthwise_cnn.conv.weight" % i) in st:

@@ -35,8 +35,9 @@ class SemanticSegmentation(object):
         if not torch.cuda.is_available():
             raise RuntimeError("SemanticSegmentation needs a GPU (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        if cfg.MODEL.TYPE != "DeepLabv3+" or cfg.MODEL.BACKBONE != "resnext50_32x4d" or cfg.MODEL.OUTPUT_STRIDE != 8:
-            raise NotImplementedError("only the reference configuration (DeepLabv3+, resnext50_32x4d, OS8) is built")
+        if cfg.MODEL.TYPE != "DeepLabv3+" or cfg.MODEL.BACKBONE != "resnext50_32x4d" or cfg.MODEL.OUTPUT_STRIDE not in (8, 16):
+            raise NotImplementedError("only the reference configuration (DeepLabv3+, resnext50_32x4d; output stride 8, or 16) is built")
+        self.output_stride = int(cfg.MODEL.OUTPUT_STRIDE)
         self.cfg = cfg
         self.num_classes = cfg.DATASET.NUM_CLASSES
         self.precision = getattr(cfg.MODEL, "PRECISION", "mixed")
@@ -90,7 +91,7 @@ class SemanticSegmentation(object):
 
     def _build(self, h, w, rung, raw_frame=None):
         """rung: a plan of the ladder ("mixed", "mixed+lo", "split16") or a plain precision ("f32", "f16", "bf16")"""
-        kw = dict(device=self.device, num_classes=self.num_classes, raw_frame=raw_frame)
+        kw = dict(device=self.device, num_classes=self.num_classes, raw_frame=raw_frame, output_stride=self.output_stride)
         if rung in ("f32", "f16", "bf16"):
             return SegNet(self.state, h, w, precision=rung, **kw)
         if rung == "split16":
