@@ -30,9 +30,9 @@ def rnd(x, kind):
         hi = x.to(torch.float16).to(torch.float32)
         lo = (x - hi).to(torch.float16).to(torch.float32)
         return hi + lo
-    if kind in ("f16q4", "f16q6"):      # f16 plane + the lo part as an MX-FP4 / FP6 copy only (blocks of 32 channels): the trunk as stored
+    if kind in ("f16q4", "f16q6", "f16q8"):      # f16 plane + the lo part as an MX-FP4 / FP6 / FP8 copy only (blocks of 32 channels): the trunk as stored
         hi = x.to(torch.float16).to(torch.float32)
-        return hi + mx_quant(x - hi, 1, "fp4" if kind == "f16q4" else "fp6")
+        return hi + mx_quant(x - hi, 1, {"f16q4": "fp4", "f16q6": "fp6", "f16q8": "fp8"}[kind])
     if kind == "bf16x2":
         hi = x.to(torch.bfloat16).to(torch.float32)
         lo = (x - hi).to(torch.bfloat16).to(torch.float32)
@@ -59,6 +59,14 @@ def mx_quant(t, dim, fmt="fp4"):
     if os.environ.get("PS_SCALE", "bump") == "bump":                 # the rule the kernels use (seg_types.h mx_fp4_scale_byte); "floor": OCP's
         scale = torch.where(amax / scale > (float(os.environ.get("PS_SAT_T", "6.5")) if fmt == "fp4" else 7.5), scale * 2, scale)
     v = (b / scale)
+    if fmt == "fp8":
+        # OCP e4m3 (bias 7, max 448) under an E8M0 block scale that puts the block maximum into [256, 512): round to nearest by float arithmetic
+        scale8 = torch.exp2(torch.floor(torch.log2(amax)) - 8.0)
+        v8 = (b / scale8).clamp(-448.0, 448.0)
+        e = torch.floor(torch.log2(v8.abs().clamp_min(2.0 ** -9))).clamp_min(-6.0)          # subnormals below 2^-6
+        step = torch.exp2(e - 3.0)
+        q = (torch.round(v8 / step) * step * scale8).reshape(*shp[:-1], k + pad)[..., :k]
+        return q.movedim(-1, dim)
     if fmt == "fp4":
         grid = torch.tensor([0, 0.5, 1, 1.5, 2, 3, 4, 6.0])
     else:
@@ -105,7 +113,7 @@ def forward(st, image_u8, pol):
         wk = pol(stage, "w")
         if wk.startswith("mx") and w.shape[2] == 1 and not kw.get("groups"):
             # main pass on f16 hi parts, correction passes on MX-quantised operands: Q(W lo) Q(x hi) [+ Q(W hi) Q(x lo)]
-            fmt = "fp6" if wk.endswith("6") else "fp4"
+            fmt = "fp6" if wk.endswith("6") else ("fp8" if wk.endswith("8") else "fp4")
             w32 = w.to(torch.float32)
             wh = rnd(w32, "f16")
             wl = (w.to(torch.float64) - wh.to(torch.float64)).to(torch.float32)
@@ -357,7 +365,13 @@ def main():
         report("  ... but aspp depthwise stage f16", Policy(X, **{"aspp.b1.dw": "f16", "aspp.b2.dw": "f16", "aspp.b3.dw": "f16"}))
         report("  ... but the decoder's tensors one f16 plane", Policy(X, **{"dec:a": "f16"}))
         report("  ... but weights one f16 plane", Policy(X, **{":w": "f16"}))
-        report("  ... stem f16 + conv1 outputs f16 (today's split16)", Policy(X, **blocks(ALL, "conv1", {"stem": "f16"}, "f16")))
+        report("  ... stem f16 + conv1 outputs f16 (round 4's split16)", Policy(X, **blocks(ALL, "conv1", {"stem": "f16"}, "f16")))
+        # what would a cheaper complete pipeline look like?  lo parts as block-scaled FP8 (e4m3: 4 significant bits on a 2^-11 term; the
+        # scaled matrix cores run FP8 at twice the f16 rate: 1 + 1/2 + 1/2 = 2 passes instead of 3)
+        report("every tensor f16 + FP8(lo), weights x2", Policy("f16q8", **{":w": X}))
+        report("every tensor f16 x2, 1x1 weights f16 + FP8(lo) products", Policy(X, **{":w": "mx8"}))
+        report("every tensor f16 + FP8(lo), 1x1 corrections in FP8", Policy("f16q8", **{":w": "mx8"}))
+        report("every tensor f16 + FP6(lo), weights x2", Policy("f16q6", **{":w": X}))
     if sel == "r3s":
         def blocks(which, conv, dd):
             for li, b in which:
