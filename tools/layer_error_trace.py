@@ -7,7 +7,6 @@ backbone block, the ASPP and the decoder) and compares the hi (+ f16 lo) planes 
 prints per stage: max |d| / max |ref| over the tensor, and the worst PER-CHANNEL figure max_c (max |d_c| / max |ref_c|) -- with
 heavy-tailed channel scales a small channel can be wrong by 100 % without showing in the first number."""
 import argparse
-import ctypes as C
 import os
 import sys
 
@@ -19,8 +18,7 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests")))
 import _full_size as fs  # noqa: E402
 from oracle import network_oracle as no  # noqa: E402
-from vision_semantic_segmentation_amd import _lib  # noqa: E402
-from vision_semantic_segmentation_amd.network import AvlSegOp, SegNet  # noqa: E402
+from vision_semantic_segmentation_amd.network import SegNet  # noqa: E402
 
 
 def oracle_stages(st, img):
@@ -43,16 +41,6 @@ def oracle_stages(st, img):
     return out
 
 
-def tensor_at(net, ptr, rows, cols, ld, dtype):
-    es = torch.tensor([], dtype=dtype).element_size()
-    for t in net._keep + [net.logits_buf]:
-        lo, hi = t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()
-        if lo <= ptr < hi:
-            flat = t.reshape(-1).view(torch.uint8)[ptr - lo:].view(dtype)
-            return torch.as_strided(flat, (rows, cols), (ld, 1)).float().cpu()
-    raise KeyError("pointer %x not in the plan's buffers" % ptr)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--heavy", type=int, default=None)
@@ -68,7 +56,6 @@ def main():
     opts = dict((kv.split("=")[0], bool(int(kv.split("=")[1]))) for kv in a.opts.split(",") if kv)
     net = SegNet(st, h, w, precision=a.precision, device="cuda:0", **opts)
     net.image.copy_(torch.from_numpy(img).cuda())
-    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ends = {}
     for i, n in enumerate(net.op_names):
         for key in ref:
@@ -76,19 +63,10 @@ def main():
                 ends[key] = i
         if n.startswith("decoder.refine_layers.") and net.ops[i].out_f32:
             ends["logits"] = i
-    dt = torch.float32 if a.precision == "f32" else (torch.bfloat16 if a.precision == "bf16" else torch.float16)
     for key, k in sorted(ends.items(), key=lambda kv: kv[1]):
-        plan = C.c_void_p()
-        arr = (AvlSegOp * (k + 1))(*net.ops[:k + 1])
-        _lib.check(_lib.lib().avl_seg_plan_create(arr, k + 1, C.byref(plan)), "create")
-        _lib.check(_lib.lib().avl_seg_plan_run(plan, s), "run")
-        torch.cuda.synchronize()
-        op = net.ops[k]
-        rows, cols = op.out_h * op.out_w, op.out_c
-        got = tensor_at(net, op.out, rows, cols, op.out_ld, torch.float32 if op.out_f32 else dt)
-        if op.out_lo:
-            got = got + tensor_at(net, op.out_lo, rows, cols, op.out_ld, dt)
-        _lib.lib().avl_seg_plan_destroy(plan)
+        net.run_prefix(k + 1)
+        got = net.op_output(k)
+        rows, cols = got.shape
         r = ref[key][0].permute(1, 2, 0).reshape(rows, cols)
         d = (got - r).abs()
         per_c = (d.amax(dim=0) / r.abs().amax(dim=0).clamp_min(1e-30))
