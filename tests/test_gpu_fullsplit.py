@@ -118,3 +118,27 @@ def test_full_split_holds_1e3_on_calibrated_heavy_tailed_weights(wseed, cuda_dev
     agree = float((got.argmax(0) == ref.argmax(0)).float().mean())
     print("full_split, heavy-tailed calibrated weights %d at %dx%d: %.2e of max|logit|, arg-max agreement %.4f" % (wseed, h, w, err, agree))
     assert err <= 1e-3 and agree >= 0.998
+
+
+def test_full_split_plan_with_the_preprocessing_stem(cuda_device):
+    """the split stem with the node's pre-processing in its loader (k_stem_mfma<f16, PRE, SPLIT>: raw BGR frame in): same bits as
+    avl_preprocess_image followed by the plain full_split plan"""
+    import torch
+    import _full_size as fs
+    from vision_semantic_segmentation_amd.camera import camera_setup_1
+    from vision_semantic_segmentation_amd.network import SegNet
+    from vision_semantic_segmentation_amd.vision_semantic_segmentation_node import preprocess_device
+    rng = np.random.default_rng(77)
+    bgr = rng.integers(0, 256, size=(192, 256, 3), dtype=np.uint8)
+    cam = camera_setup_1().scaled(256 / 1920.0, 192 / 1440.0)
+    st = fs.state_dict(0)
+    for factor in (1, 2):
+        rgb = preprocess_device(bgr, cam, factor)
+        h, w = int(rgb.shape[0]), int(rgb.shape[1])
+        plain = SegNet(st, h, w, precision="mixed", device=cuda_device, full_split=True)
+        plain.forward(rgb)
+        want = plain.logits.clone()
+        raw = SegNet(st, h, w, precision="mixed", device=cuda_device, full_split=True, raw_frame=(192, 256))
+        raw.set_camera(cam.K, cam.dist)
+        raw.forward(torch.from_numpy(bgr).to(cuda_device))
+        assert torch.equal(raw.logits, want), factor
