@@ -161,3 +161,40 @@ def test_self_check_decision_table():
     rung, err, warn = S.decide_rung(bad3, "warn")
     assert rung == "split16" and err == 3e-2 and "keeping" in warn
     assert S.decide_rung(bad3[:2], "warn")[0] == "f32"                 # nothing finite to keep
+
+
+def test_bottleneck_weights_are_packed_in_mfma_fragment_order():
+    """network.pack_bottleneck (AVL_OP_BOTTLENECK, seg_bottleneck.hip): lane l of a fragment holds MFMA row l & 15 and K values
+    8 (l >> 4) .. + 7 of a 32-wide step; the 3x3 as block-diagonal 16-channel windows whose K step is two taps x 16 input channels;
+    conv3's rows permuted so that a lane owns 8 consecutive output channels; the downsample 1x1 appended as extra K steps"""
+    import torch
+    from vision_semantic_segmentation_amd.network import pack_bottleneck
+    g = torch.Generator().manual_seed(0)
+    w1 = torch.randn(128, 256, generator=g, dtype=torch.float64)
+    w2 = torch.randn(128, 4, 3, 3, generator=g, dtype=torch.float64)
+    w3 = torch.randn(256, 128, generator=g, dtype=torch.float64)
+    wd = torch.randn(256, 64, generator=g, dtype=torch.float64)
+    p1, p2, p3 = pack_bottleneck(w1, w2, w3, None, 32)
+    assert p1.dtype == torch.float16 and p1.numel() == 8 * 8 * 2 * 64 * 8 and p2.numel() == 8 * 5 * 2 * 64 * 8 and p3.numel() == 8 * 4 * 2 * 2 * 64 * 8
+    P1, P2, P3 = p1.reshape(8, 8, 2, 64, 8), p2.reshape(8, 5, 2, 64, 8), p3.reshape(8, 4, 2, 2, 64, 8)
+    hi1 = w1.to(torch.float16)
+    lo1 = (w1 - hi1.double()).to(torch.float16)
+    for n, ks, l, j in ((3, 5, 37, 6), (0, 0, 0, 0), (7, 7, 63, 7)):
+        assert P1[n, ks, 0, l, j] == hi1[n * 16 + (l & 15), ks * 32 + 8 * (l >> 4) + j]
+        assert P1[n, ks, 1, l, j] == lo1[n * 16 + (l & 15), ks * 32 + 8 * (l >> 4) + j]
+    cg = 4
+    for win, ks, l, j in ((0, 0, 0, 0), (7, 4, 63, 7), (2, 4, 20, 1), (2, 4, 40, 1), (3, 1, 17, 5), (3, 1, 33, 1), (5, 3, 53, 2)):
+        kq, o = l >> 4, win * 16 + (l & 15)
+        tap, cin = 2 * ks + (kq >> 1), win * 16 + (kq & 1) * 8 + j
+        want = 0.0
+        if tap < 9 and cin // cg == o // cg:
+            want = float(w2[o, cin % cg, tap // 3, tap % 3].to(torch.float16))
+        assert float(P2[win, ks, 0, l, j]) == want, (win, ks, l, j)
+    for wv, ks, nj, l, j in ((6, 2, 1, 45, 3), (0, 0, 0, 0, 0), (7, 3, 1, 63, 7)):
+        i = l & 15
+        ch = 32 * wv + (i >> 2) * 8 + nj * 4 + (i & 3)
+        assert P3[wv, ks, nj, 0, l, j] == w3[ch, ks * 32 + 8 * (l >> 4) + j].to(torch.float16)
+    _, _, p3d = pack_bottleneck(w1[:, :64].contiguous(), w2, w3, wd, 32)
+    P3d = p3d.reshape(8, 6, 2, 2, 64, 8)
+    assert P3d[6, 5, 1, 0, 45, 3] == wd[32 * 6 + (13 >> 2) * 8 + 4 + (13 & 3), 32 + 8 * 2 + 3].to(torch.float16)
+    assert torch.equal(P3d[:, :4], P3)

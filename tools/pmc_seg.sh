@@ -6,7 +6,9 @@ export TMPDIR=/tmp
 PREC=${1:-mixed}
 OUT=gpurun_out/pmc_seg
 rm -rf $OUT; mkdir -p $OUT
+# usage: bash tools/pmc_seg.sh [precision] [mixed options, e.g. full_split=1]
 ARGS="tools/profile_seg.py --reps 1 --top 1 --precision $PREC"
+if [ -n "$2" ]; then ARGS="$ARGS --mixed-opts $2"; fi
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/p1 -- python3 $ARGS > $OUT/p1.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/p2 -- python3 $ARGS > $OUT/p2.log 2>&1
 # (the matrix cores' busy cycles; GRBM_GUI_ACTIVE = kernel cycles summed over the 8 XCDs, its own counter block)
