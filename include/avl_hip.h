@@ -273,7 +273,9 @@ typedef struct avl_seg_op {
     int32_t in2_ld;
     int32_t ksize, stride, pad, dil, groups;
     int32_t relu;
-    int32_t out_f32;         /* GEMM: write fp32 (the logits) instead of `dtype`                */
+    int32_t out_f32;         /* GEMM: write fp32 (the logits) instead of `dtype`.  With out_mx != NULL (N <= 32, no residual, no ReLU): out_mx is
+                                uint8 labels[out_rows] and the epilogue also writes torch.argmax over each row's N logits there (first maximal
+                                index wins, a NaN counts as maximal; semantic_segmentation.py:56) -- AVL_OP_ARGMAX without its launch */
     int32_t w_rows;          /* GEMM: rows of `weight` allocated (out_c padded to the N tile)   */
     int32_t w_layout;        /* GCONV: 0 = float [group][tap][ci][co] (direct kernel),
                                        1 = bf16 block-diagonal 32-channel windows [window][2][9][16][32] (MFMA kernel)

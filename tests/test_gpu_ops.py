@@ -365,3 +365,44 @@ def test_fused_depthwise_pointwise_repeats_under_load(case, cuda_device):
                     assert torch.equal(o, ref), "launch ~%d differs from the first one" % i
     finally:
         _lib.lib().avl_seg_plan_destroy(plan)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_classifier_gemm_writes_the_argmax(precision, cuda_device):
+    """round 5: torch.argmax (semantic_segmentation.py:56) in the classifier GEMM's epilogue (out_f32 with out_mx = uint8 labels): the
+    labels are the arg-max of the very logits stored, the FIRST maximal index wins on ties -- inside one lane's 16 channels and across
+    the two lanes of a row (classes 0-15 | 16-18) --, rows past M stay untouched"""
+    import torch
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import OP_GEMM, AvlSegOp
+    tdt, did, _ = _dt(precision)
+    M, K, N = 1000, 256, 19
+    Mp = 1024
+    g = torch.Generator().manual_seed(5)
+    a = torch.zeros((Mp, K), dtype=tdt)
+    a[:M] = torch.randn((M, K), generator=g).to(tdt)
+    w = torch.zeros((64, K), dtype=tdt)
+    w[:N] = (torch.randn((N, K), generator=g) * 0.05).to(tdt)
+    w[7] = w[3]                     # ties inside the first lane's block ...
+    w[17] = w[16]                   # ... inside the second ...
+    w[18] = w[5]                    # ... and across the two
+    b = torch.zeros(64)
+    b[:N] = torch.randn(N, generator=g) * 0.01
+    b[7], b[17], b[18] = b[3], b[16], b[5]
+    ad, wd, bd = a.to(cuda_device), w.to(cuda_device), b.to(cuda_device)
+    logits = torch.full((Mp, N), -7.0, dtype=torch.float32, device=cuda_device)
+    labels = torch.full((Mp,), 99, dtype=torch.uint8, device=cuda_device)
+    op = AvlSegOp()
+    op.kind, op.dtype = OP_GEMM, did
+    op.in_, op.out, op.weight, op.bias, op.out_mx = ad.data_ptr(), logits.data_ptr(), wd.data_ptr(), bd.data_ptr(), labels.data_ptr()
+    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = 1, M, K, K, Mp
+    op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = 1, M, N, N, Mp
+    op.relu, op.out_f32, op.w_rows, op.ksize, op.stride, op.dil, op.groups = 0, 1, 64, 1, 1, 1, 1
+    _run_plan([op])
+    lg = logits[:M].cpu()
+    want = torch.argmax(lg, dim=1)
+    # torch.argmax returns the first maximal index on CPU
+    assert torch.equal(labels[:M].cpu().long(), want)
+    assert torch.all(labels[M:] == 99) and torch.all(logits[M:] == -7.0)
+    assert bool(((lg[:, 3] == lg[:, 7]) & (lg[:, 16] == lg[:, 17]) & (lg[:, 5] == lg[:, 18])).all())       # the ties are real
+    assert set(want.tolist()) & {3, 16, 5} and not (set(want.tolist()) & {7, 17, 18})

@@ -45,6 +45,9 @@ struct GemmArgs {
     long long a_lo_delta;
     const void* R_lo;
     void* C_lo;
+    // k_gemm with out_f32 and N <= 32 (the classifier): torch.argmax over the row's N values (semantic_segmentation.py:56: first maximal
+    // index wins, a NaN counts as maximal) written here as one byte per row, from the very values stored as logits; NULL = not wanted
+    unsigned char* labels;
 };
 
 // which sub-steps of a K block bring a NEW activation tile (the others reuse the tile already in LDS)
@@ -175,6 +178,25 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm(GemmArgs p) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + nbase + 4 * j);
         bias[4 * j] = b.x; bias[4 * j + 1] = b.y; bias[4 * j + 2] = b.z; bias[4 * j + 3] = b.w;
     }
+    if (p.labels) {
+        // the classifier's arg-max (N <= 32: channel blocks kq = 0 and 1 of a row sit 16 lanes apart), on the values stored below; every lane
+        // takes part in the exchange, so this runs in front of the loop whose lanes drop out individually
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * 64 + mi * 16 + fr;
+            float best = acc[mi][0][0] + bias[0];
+            int bi = nbase;
+#pragma unroll
+            for (int i = 1; i < 16; ++i) {
+                const float val = acc[mi][i >> 2][i & 3] + bias[i];
+                if (nbase + i < p.N && (val > best || (val != val && best == best))) { best = val; bi = nbase + i; }
+            }
+            const float ob = __shfl_down(best, 16);
+            const int oi = __shfl_down(bi, 16);
+            if (nbase + 16 < p.N && (ob > best || (ob != ob && best == best))) { best = ob; bi = oi; }
+            if (kq == 0 && m < p.M) p.labels[m] = (unsigned char)bi;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wm * 64 + mi * 16 + fr;
@@ -206,7 +228,8 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm(GemmArgs p) {
             float* cp = static_cast<float*>(p.C) + (long long)m * p.ldc + nbase;
             for (int i = 0; i < 16; ++i)
                 if (nbase + i < p.N) cp[i] = v[i];
-        } else {
+        }
+        if (!p.out_f32) {
             T* cp = static_cast<T*>(p.C) + (long long)m * p.ldc + nbase;
             if (full) {
                 float lo[8], hi[8];
@@ -1492,6 +1515,9 @@ int validate_gemm(const avl_seg_op& op) {
     AVL_REQUIRE(op.out_rows >= M, "GEMM writes %d rows, output has %d", M, op.out_rows);
     if (!op.out_f32) AVL_REQUIRE((op.out_ld * es) % 16 == 0 && N % 16 == 0, "GEMM out_ld %d / N %d not 16-aligned", op.out_ld, N);
     if (op.in2) AVL_REQUIRE(op.in2_ld >= N && (op.in2_ld * es) % 16 == 0, "GEMM residual ld %d", op.in2_ld);
+    if (op.out_f32 && op.out_mx)      // the fused arg-max (labels through out_mx): the small-N kernel, plain logits
+        AVL_REQUIRE(N <= 32 && !op.in2 && !op.relu && op.w_split != 2 && t.bn == 64 && !ring_eligible(op),
+                    "GEMM: an arg-max output (out_f32 with out_mx = uint8 labels[rows]) needs N <= 32, no residual, no ReLU (N %d)", N);
     if (op.w_split == 2) {
         AVL_REQUIRE(op.dtype == AVL_F16 && op.w_mx && op.in_mx, "MX GEMM needs AVL_F16 activations and the w_mx / in_mx bundles");
         AVL_REQUIRE(K % 256 == 0 && N % 256 == 0 && op.w_rows % 256 == 0 && op.w_rows >= N, "MX GEMM: K %d, N %d, w_rows %d must be multiples of 256", K, N, op.w_rows);
@@ -1543,6 +1569,7 @@ int launch_gemm(const avl_seg_op& op, hipStream_t s) {
     a.lda = op.in_ld; a.ldr = op.in2_ld; a.ldc = op.out_ld;
     a.M = op.out_h * op.out_w; a.N = op.out_c; a.K = op.in_c;
     a.relu = op.relu; a.out_f32 = op.out_f32;
+    a.labels = (op.out_f32 && op.w_split != 2) ? static_cast<unsigned char*>(op.out_mx) : nullptr;      // (out_f32 ops have no MX bundle: out_mx carries the label map)
     if (op.w_split == 2) {
         MxArgs mx;
         memset(&mx, 0, sizeof(mx));

@@ -63,7 +63,10 @@ void work(const avl_seg_op& op, double& flops, double& bytes) {
                 const double e_res = act_bytes(es, op.in2_lo != nullptr, (op.mx_flags & AVL_MX_RES_LO) != 0, false);
                 bytes += (double)op.out_c * k_all * e_w + (op.in2 ? out_pix * op.out_c * e_res : 0.0) + (op.in3 ? in_pix * op.in3_c * e_in : 0.0);
             }
-            if (op.out_f32) bytes += out_pix * op.out_c * (4 - es);
+            if (op.out_f32) {
+                bytes += out_pix * op.out_c * (4 - es);
+                if (op.out_mx) bytes += out_pix - out_pix * op.out_c * (0.5 + 1.0 / 32.0);       // out_mx = the uint8 label map of the fused arg-max, not an MX bundle
+            }
             break;
         case AVL_OP_GCONV:
             flops = 2.0 * out_pix * op.out_c * (op.in_c / op.groups) * 9;

@@ -634,7 +634,7 @@ class SegNet(object):
         return 0 if (not isinstance(a, Act) or a.lo is None) else a.lo.data_ptr() + col * a.lo.element_size()
 
     def _gemm(self, name, src, hw, cin, w, b, dst, dst_col=0, relu=True, res=None, out_f32=False, src_col=0, bias_dev=None,
-              read_lo=True, src2=None, w2=None, b2=None):
+              read_lo=True, src2=None, w2=None, b2=None, labels=None):
         """1x1 conv.  w float64 [cout][cin] (BN folded), b float64 [cout].  "mixed": weights become f16 pairs; the low
         plane of `src` is read if it has one (unless read_lo = False), `res` and `dst` are used with all the planes they have."""
         h, wd = hw
@@ -698,6 +698,9 @@ class SegNet(object):
                 if isinstance(t_, Act) and t_.lo_fp4:
                     raise RuntimeError("%s: the %s keeps its lo part as FP4 only, which needs the MX GEMM" % (name, what))
         f["mx_flags"] = flags
+        if labels is not None:
+            assert out_f32 and not use_mx and res is None and not relu
+            f["out_mx"] = labels.data_ptr()
         self._op(name, OP_GEMM, **f)
 
     def _bottleneck(self, p, st, x, hw, cin, width, cout, y):
@@ -1064,10 +1067,12 @@ class SegNet(object):
         self.logits_buf = torch.zeros((_round_up(Mo, self.ROW_PAD), self.num_classes), dtype=torch.float32, device=dev)
         self.labels_buf = torch.zeros(_round_up(Mo, self.ROW_PAD), dtype=torch.uint8, device=dev)
         self._keep += [self.logits_buf, self.labels_buf]
-        self._gemm(p, x, hw, cin, w, b, Act(self.logits_buf), relu=False, out_f32=True)
-        self._op("argmax", OP_ARGMAX, dtype=_lib.AVL_F32, in_=self.logits_buf.data_ptr(), out=self.labels_buf.data_ptr(), in_h=hw[0], in_w=hw[1],
-                 in_c=self.num_classes, in_ld=self.num_classes, in_rows=self.logits_buf.shape[0], out_h=hw[0], out_w=hw[1], out_c=1,
-                 out_ld=1, out_rows=self.labels_buf.shape[0])
+        # the arg-max (semantic_segmentation.py:56) rides in the classifier's epilogue: the 19 logits of a pixel sit in two lanes' registers there
+        self._gemm(p, x, hw, cin, w, b, Act(self.logits_buf), relu=False, out_f32=True, labels=self.labels_buf if self.num_classes <= 32 else None)
+        if self.num_classes > 32:
+            self._op("argmax", OP_ARGMAX, dtype=_lib.AVL_F32, in_=self.logits_buf.data_ptr(), out=self.labels_buf.data_ptr(), in_h=hw[0], in_w=hw[1],
+                     in_c=self.num_classes, in_ld=self.num_classes, in_rows=self.logits_buf.shape[0], out_h=hw[0], out_w=hw[1], out_c=1,
+                     out_ld=1, out_rows=self.labels_buf.shape[0])
 
     # -------------------------------------------------------------------------------- running
     @property
