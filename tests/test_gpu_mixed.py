@@ -231,6 +231,62 @@ def test_exact_fused_depthwise_pointwise(case, cuda_device):
     assert torch.all(out[:, M:] == 7.0)
 
 
+@pytest.mark.parametrize("case", [(37, 53, 512, 256, 1, 0), (20, 31, 256, 256, 1, 0), (30, 40, 1024, 256, 12, 12), (16, 16, 64, 512, 1, 1), (9, 140, 128, 64, 2, 0)])
+def test_exact_fused_depthwise_pointwise_with_a_split_input(case, cuda_device):
+    """round 5: AVL_OP_DWPW with w_split = 2 AND in_lo (k_dwpw_xs: the mixed decoder's refine blocks decoder.py:33-43 -- pad 0 --, the
+    split16 plan's ASPP branches): input hi + lo planes, (xh + xl)(wh + wl) without the lo x lo term (2^-22), everything else as
+    k_dwpw_x -- against a float64 evaluation of the same operands.  Cases: the decoder's two shapes, a dilated padded branch, two
+    output-channel tiles, a tile spanning several image rows with K = 2 steps."""
+    import torch
+    import torch.nn.functional as F
+    from test_gpu_ops import _from_rows, _nhwc_rows
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import OP_DWPW, AvlSegOp, dwpw_tile_order, pack_dw_pairs_split, pack_split_rows, split_f16
+    H, W, K, N, d, pad = case
+    OH, OW = H + 2 * pad - 2 * d, W + 2 * pad - 2 * d
+    g = torch.Generator().manual_seed(H * 31 + W + K + d + 7)
+    x = torch.randn((1, K, H, W), generator=g, dtype=torch.float64)
+    xh, xl = _split(x)
+    w1 = (torch.randn((K, 1, 3, 3), generator=g) * 0.3).double()
+    b1 = (torch.randn(K, generator=g) * 0.1).double()
+    w2 = torch.randn((N, K), generator=g, dtype=torch.float64) / K ** 0.5
+    b2 = torch.randn(N, generator=g) * 0.1
+    M = OH * OW
+    Mp, Np = (M + 255) // 256 * 256, (N + 255) // 256 * 256
+    src = torch.stack([_nhwc_rows(xh), _nhwc_rows(xl)]).to(cuda_device)
+    w2p = torch.zeros((Np, K), dtype=torch.float64)
+    w2p[:N] = w2
+    b2p = torch.zeros(Np)
+    b2p[:N] = b2
+    w2d, b2d = pack_split_rows(w2p, 2).to(cuda_device), b2p.to(cuda_device)
+    out = torch.full((2, Mp, N), 7.0, dtype=torch.float16, device=cuda_device)
+    params = torch.cat([pack_dw_pairs_split(w1, b1), dwpw_tile_order(OH, OW, d)]).to(cuda_device)
+    op = AvlSegOp()
+    op.kind, op.dtype = OP_DWPW, _lib.AVL_F16
+    op.in_, op.in_lo, op.in2, op.out, op.out_lo = src[0].data_ptr(), src[1].data_ptr(), params.data_ptr(), out[0].data_ptr(), out[1].data_ptr()
+    op.weight, op.bias, op.w_split = w2d.data_ptr(), b2d.data_ptr(), 2
+    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = H, W, K, K, src.shape[1]
+    op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = OH, OW, N, N, Mp
+    op.relu, op.w_rows, op.ksize, op.stride, op.pad, op.dil, op.groups = 1, Np, 3, 1, pad, d, K
+    _run_plan([op])
+    w1h, w1l = split_f16(w1.reshape(K, 9))
+    w1s = (w1h.double() + w1l.double()).reshape(K, 1, 3, 3)
+    b1s = b1.to(torch.float32).double()
+    a64 = F.relu(F.conv2d(xh.double() + xl.double(), w1s, b1s, padding=pad, dilation=d, groups=K))
+    ah, al = _split(a64)
+    w_hi, w_lo = _split(w2)
+    ref = F.relu(F.conv2d(ah.double() + al.double(), (w_hi.double() + w_lo.double()).view(N, K, 1, 1), b2.double()))
+    got = _from_rows(out[0].cpu().double() + out[1].cpu().double(), OH, OW, N)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print("exact dwpw, split input %s: %.3e" % (case, err))
+    assert err <= 2 * TOL, "exact dwpw, split input %s: %.3e" % (case, err)
+    assert torch.all(out[:, M:] == 7.0)
+    # and the lo plane matters: the same launch on the hi plane alone is off by the input's rounding
+    a_hi_only = F.relu(F.conv2d(xh.double(), w1s, b1s, padding=pad, dilation=d, groups=K))
+    ref_hi = F.relu(F.conv2d(a_hi_only, (w_hi.double() + w_lo.double()).view(N, K, 1, 1), b2.double()))
+    assert float((got - ref_hi).abs().max() / ref.abs().max()) > 10 * err
+
+
 @pytest.mark.parametrize("case", [(37, 53, 64, 1, 0), (20, 31, 512, 1, 0), (9, 9, 64, 2, 2)])
 def test_split_depthwise_and_bilinear(case, cuda_device):
     import torch
@@ -410,7 +466,7 @@ def test_mixed_logits_with_layer1_lo_planes(state, cuda_device):
         errs.append(float((got - ref).abs().max() / ref.abs().max()))
     print("mixed 320x416: layer1 lo planes off / on: max rel err %.3e / %.3e" % tuple(errs))
     assert los == [1, 3]                       # conv3 outputs of layer1 that carry a lo plane
-    assert errs[0] <= 9e-4 and errs[1] <= errs[0] * 1.05      # (the fused blocks' conv1 never reads the lo plane: it enters the residual sum only)
+    assert errs[0] <= 9e-4 and errs[1] <= errs[0] * 1.15      # (max-norm errors of two plans 2^-12 apart in one tensor class are not ordered; the fused blocks' conv1 never reads the lo plane: it enters the residual sum only)
 
 
 def _bundle(hi64, lo64, rows_pad):

@@ -18,6 +18,14 @@
 namespace avl {
 namespace {
 
+// DW_EXP (tools/ab_dwpw.sh; 0 in every shipped build): phase ablations of k_dwpw_x / k_dwpw_xs for timing only (results are wrong) --
+// bit 0: no MFMAs, bit 1: no depthwise arithmetic (zero tiles), bit 2: no tap loads, bit 3: no fragment reads from LDS (with bit 0);
+// k_dwpw_xs only: bit 7: no result stores
+#ifndef DW_EXP
+#define DW_EXP 0
+#endif
+// (bit 8: depthwise parameters are constants instead of LDS reads)
+#define DW_PARAM(T, ptr) ((DW_EXP & 256) ? T{} : *reinterpret_cast<const T*>(ptr))
 constexpr int TM = 128;              // pixels per workgroup
 constexpr int TN = 256;              // output channels per workgroup
 constexpr int A_STAGE = TM * 128;    // 16 KB: 128 rows x 64 k x 2 B
@@ -27,6 +35,7 @@ constexpr int P_STEP = 8 * 6 * 8 * 4;                                         //
 
 struct DwPwArgs {
     const void* X;
+    const void* X_lo;        // k_dwpw_xs: low plane of the input (same row stride), else NULL
     const void* W;
     const float* bias;
     const uint32_t* dwp;     // [K/64][chunk 8][6][8] dwords: 5 tap pairs (lo = tap 2p, hi = tap 2p+1, 16-bit type) + fp32 bias
@@ -348,22 +357,31 @@ __global__ void __launch_bounds__(512) k_dwpw_x(DwPwArgs p) {
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.X), 0, (int)p.x_bytes, 0x00020000);
     auto load_taps = [&](int s, int q) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) raw[q][t] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)voff[q][t], s * 128, 0);
+        for (int t = 0; t < 9; ++t) raw[q][t] = (DW_EXP & 4) ? v4i{0, 0, 0, 0} : __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)voff[q][t], s * 128, 0);
     };
 
     // depthwise 3x3 of K-step s for pixel q of this lane: fp32 sums of f16 x (f16 hi + f16 lo) products -> hi tile slot s & 1, lo tile
     auto produce_a = [&](int s, int q) {
+        if constexpr ((DW_EXP & 2) != 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) asm volatile("" :: "v"(raw[q][t]));
+            const int row = r0 + q * 64;
+            const int sw = row * 128 + ((chunk ^ (row & 7)) << 4);
+            *reinterpret_cast<v4i*>(lds + X_LDS_AH + (s & 1) * A_STAGE + sw) = v4i{0, 0, 0, 0};
+            *reinterpret_cast<v4i*>(lds + X_LDS_AL + sw) = v4i{0, 0, 0, 0};
+            return;
+        }
         const uint32_t* pp = reinterpret_cast<const uint32_t*>(lds + X_LDS_P + (s & (XP_RING - 1)) * XP_STEP + chunk * (11 * 8 * 4));
         float o[8];
         {
-            const float4 b0 = *reinterpret_cast<const float4*>(pp + 10 * 8), b1 = *reinterpret_cast<const float4*>(pp + 10 * 8 + 4);
+            const float4 b0 = DW_PARAM(float4, pp + 10 * 8), b1 = DW_PARAM(float4, pp + 10 * 8 + 4);
             o[0] = b0.x; o[1] = b0.y; o[2] = b0.z; o[3] = b0.w;
             o[4] = b1.x; o[5] = b1.y; o[6] = b1.z; o[7] = b1.w;
         }
 #pragma unroll
         for (int pr = 0; pr < 5; ++pr) {
-            const uint4 h0 = *reinterpret_cast<const uint4*>(pp + pr * 8), h1 = *reinterpret_cast<const uint4*>(pp + pr * 8 + 4);
-            const uint4 l0 = *reinterpret_cast<const uint4*>(pp + (5 + pr) * 8), l1 = *reinterpret_cast<const uint4*>(pp + (5 + pr) * 8 + 4);
+            const uint4 h0 = DW_PARAM(uint4, pp + pr * 8), h1 = DW_PARAM(uint4, pp + pr * 8 + 4);
+            const uint4 l0 = DW_PARAM(uint4, pp + (5 + pr) * 8), l1 = DW_PARAM(uint4, pp + (5 + pr) * 8 + 4);
             const uint32_t wh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
             const uint32_t wlo[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
             const v4i ra = raw[q][2 * pr], rb = raw[q][pr < 4 ? 2 * pr + 1 : 8];
@@ -420,11 +438,11 @@ __global__ void __launch_bounds__(512) k_dwpw_x(DwPwArgs p) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<HT>::mfma(wa[nj], al[mi], acc[mi][nj]);
+                for (int nj = 0; nj < 4; ++nj) { if constexpr (!(DW_EXP & 1)) acc[mi][nj] = Half16<HT>::mfma(wa[nj], al[mi], acc[mi][nj]); else if constexpr (!(DW_EXP & 8)) asm volatile("" :: "v"(wa[nj]), "v"(al[mi])); }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<HT>::mfma(wa[nj], ah[mi], acc[mi][nj]);
+                for (int nj = 0; nj < 4; ++nj) { if constexpr (!(DW_EXP & 1)) acc[mi][nj] = Half16<HT>::mfma(wa[nj], ah[mi], acc[mi][nj]); else if constexpr (!(DW_EXP & 8)) asm volatile("" :: "v"(wa[nj]), "v"(ah[mi])); }
         }
         store_w(2 * s + 1);
         store_p(s + 3);
@@ -443,7 +461,7 @@ __global__ void __launch_bounds__(512) k_dwpw_x(DwPwArgs p) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = Half16<HT>::mfma(wa[nj], ah[mi], acc[mi][nj]);
+                for (int nj = 0; nj < 4; ++nj) { if constexpr (!(DW_EXP & 1)) acc[mi][nj] = Half16<HT>::mfma(wa[nj], ah[mi], acc[mi][nj]); else if constexpr (!(DW_EXP & 8)) asm volatile("" :: "v"(wa[nj]), "v"(ah[mi])); }
             if (more) {
                 produce_a(s + 1, kk);
                 if (more2) load_taps(s + 2, kk);
@@ -491,6 +509,275 @@ int launch_dwpw_x(const DwPwArgs& a, hipStream_t s) {
     return AVL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_dwpw_xs: k_dwpw_x for an input that is itself split (hi + lo f16 planes) -- the "mixed" decoder's two refine blocks
+// (decoder.py:33-43: depthwise 3x3 pad 0 + BN + ReLU, 1x1 + BN + ReLU on concat(upsampled ASPP, low-level) and on its result) and the
+// ASPP branches of the split16 plan.  Unfused, the depthwise result went to HBM as two planes (+ FP4 copies) and came back into the
+// 1x1 GEMM: 2 x 265 MB + 2 x 131 MB per frame at 1080p for 2.7 GMAC.
+//   depthwise stage: (xh + xl) . (wh + wl) as xl.wh + xh.wl + xh.wh, three v_dot2c per tap pair and channel, fp32 sums (small terms first);
+//   the tap registers hold ONE pixel's nine taps of both planes (72 VGPRs, as many as k_dwpw_x's two pixels of one plane): pixel 0 of
+//   slice s + 1 is produced during sub-step j = 0 of step s and pixel 1 during j = 1, each pixel's taps requested as soon as the other
+//   pixel's registers are free (48 MFMAs per wave ahead of their use); the lo tile has two slots like the hi tile for that;
+//   weight sub-slices and depthwise parameters come by LDS-DMA (no staging registers: 214 VGPRs).
+//   LDS: weight ring 2 x 32 KB | hi tiles 2 x 16 KB | lo tiles 2 x 16 KB | parameter ring 4 x 2.75 KB = 139 KB.
+constexpr int S_LDS_W = 0, S_LDS_AH = 2 * W_STAGE, S_LDS_AL = S_LDS_AH + 2 * A_STAGE, S_LDS_P = S_LDS_AL + 2 * A_STAGE;
+
+__global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
+    typedef f16 HT;
+    typedef typename Half16<HT>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nt = blockIdx.x % p.ntiles;
+    const int bm = blockIdx.x / p.ntiles, slot = (bm & 7) * p.per_xcd + (bm >> 3);
+    if (slot >= p.mtiles) return;
+    const int mt = p.order[slot];
+    const int nk = p.K / 64;
+
+    const unsigned lds0 = lds_addr(lds);
+    // ---- depthwise parameters: K-step s -> ring slot s & 3; 2816 bytes = 176 lanes x 16 bytes, by LDS-DMA (waves 0 .. 2)
+    auto dma_p = [&](int s) {
+        if (tid < XP_STEP / 16 && s < nk)
+            glds16_saddr(reinterpret_cast<const char*>(p.dwp) + s * XP_STEP, (unsigned)tid * 16u, lds0 + S_LDS_P + (s & (XP_RING - 1)) * XP_STEP + wave * 1024);
+    };
+    for (int s = 0; s < 3; ++s) dma_p(s);
+    // ---- producer geometry: lane -> 8-channel chunk of two pixels (rows r0, r0 + 64 of the tile).  A tap's byte offset is the pixel's
+    // base (tap 0, possibly outside the image: signed) + a wave-uniform step; a 9-bit mask says which taps exist (the others get an
+    // out-of-range offset and read as 0): 4 VGPRs instead of k_dwpw_x's 18, which this kernel does not have
+    const int chunk = tid & 7, r0 = tid >> 3;
+    int vbase[2];
+    unsigned vmask[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int m = mt * TM + r0 + q * 64;
+        const int y = m / p.OW, x = m - y * p.OW;
+        vbase[q] = (int)((((long long)(y - p.pad) * p.Wd + (x - p.pad)) * p.ldx + chunk * 8) * 2);
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = y - p.pad + (t / 3) * p.dil, ix = x - p.pad + (t % 3) * p.dil;
+            mk |= (unsigned)((m < p.M) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd)) << t;
+        }
+        vmask[q] = mk;
+    }
+    const int tstep_x = p.dil * p.ldx * 2, tstep_y = p.dil * p.Wd * p.ldx * 2;
+    // ---- pointwise weight sub-slices (256 rows x 128 B: rows [K/64][hi 64 | lo 64]) by LDS-DMA: instruction i of a wave brings rows
+    // 64 i + 8 wave .. + 7 (1 KB, linear in LDS); the swizzle goes on the SOURCE chunk (its key does not depend on i)
+    const char* wbase = static_cast<const char*>(p.W) + (long long)nt * TN * p.K * 4;
+    unsigned w_voff;
+    {
+        const int r = wave * 8 + (lane >> 3);
+        const int key = ((r >> 1) & 1) | (((r >> 4) & 3) << 1);
+        w_voff = (unsigned)(r * p.K * 4 + (((lane & 7) ^ key) << 4));
+    }
+    const int w_rows64 = 64 * p.K * 4;
+    auto dma_w = [&](int h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_saddr(wbase + h * 128 + i * w_rows64, w_voff, lds0 + S_LDS_W + (h & 1) * W_STAGE + i * 8192 + wave * 1024);
+    };
+    // (the swizzle keys do not depend on mi / nj: row & 7 = fr & 7 for the tiles, bits (fr >> 1) & 1 and (fr >> 2) & 3 for the weights --
+    //  one address per K half each, the rest are immediate offsets)
+    const int fr = lane & 15, kq = lane >> 4;
+    int a_sw[2], w_sw[2];
+    {
+        const int a_key = fr & 7, w_key = ((fr >> 1) & 1) | (((fr >> 2) & 3) << 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            a_sw[kk] = (wm * 64 + fr) * 128 + (((kk * 4 + kq) ^ a_key) << 4);
+            w_sw[kk] = S_LDS_W + (wn * 64 + (fr >> 2) * 16 + (fr & 3)) * 128 + (((kk * 4 + kq) ^ w_key) << 4);
+        }
+    }
+    f32x4 acc[4][4];
+    {
+        const int nb = nt * TN + wn * 64 + kq * 16;
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + nb + 4 * nj);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[mi][nj] = f32x4{b.x, b.y, b.z, b.w};
+        }
+    }
+
+    // one pixel's taps of both planes (all loads compiler-visible: hipcc counts the vmcnt waits, see k_dwpw)
+    v4i rh[9], rl[9];
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.X), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xlrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.X_lo), 0, (int)p.x_bytes, 0x00020000);
+    auto load_taps = [&](int s, int q) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int off = (vmask[q] >> t) & 1u ? vbase[q] + (t / 3) * tstep_y + (t % 3) * tstep_x : 0x7fffff00;   // >= x_bytes: reads as 0
+            rh[t] = (DW_EXP & 4) ? v4i{off, 0, 0, 0} : __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, s * 128, 0);
+            rl[t] = (DW_EXP & 4) ? v4i{off, 0, 0, 0} : __builtin_amdgcn_raw_buffer_load_b128(xlrsrc, off, s * 128, 0);
+        }
+    };
+
+    // depthwise 3x3 of K-step s for pixel q of this lane -> hi / lo tile slot s & 1
+    auto produce_a = [&](int s, int q) {
+        if constexpr ((DW_EXP & 2) != 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) asm volatile("" :: "v"(rh[t]), "v"(rl[t]));
+            const int row = r0 + q * 64;
+            const int sw = (s & 1) * A_STAGE + row * 128 + ((chunk ^ (row & 7)) << 4);
+            *reinterpret_cast<v4i*>(lds + S_LDS_AH + sw) = v4i{0, 0, 0, 0};
+            *reinterpret_cast<v4i*>(lds + S_LDS_AL + sw) = v4i{0, 0, 0, 0};
+            return;
+        }
+        const uint32_t* pp = reinterpret_cast<const uint32_t*>(lds + S_LDS_P + (s & (XP_RING - 1)) * XP_STEP + chunk * (11 * 8 * 4));
+        float o[8];
+        {
+            const float4 b0 = DW_PARAM(float4, pp + 10 * 8), b1 = DW_PARAM(float4, pp + 10 * 8 + 4);
+            o[0] = b0.x; o[1] = b0.y; o[2] = b0.z; o[3] = b0.w;
+            o[4] = b1.x; o[5] = b1.y; o[6] = b1.z; o[7] = b1.w;
+        }
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const uint4 h0 = DW_PARAM(uint4, pp + pr * 8), h1 = DW_PARAM(uint4, pp + pr * 8 + 4);
+            const uint4 l0 = DW_PARAM(uint4, pp + (5 + pr) * 8), l1 = DW_PARAM(uint4, pp + (5 + pr) * 8 + 4);
+            const uint32_t wh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            const uint32_t wlo[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+            const v4i ra = rh[2 * pr], rb = rh[pr < 4 ? 2 * pr + 1 : 8];
+            const v4i la = rl[2 * pr], lb = rl[pr < 4 ? 2 * pr + 1 : 8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t ua = (uint32_t)ra[j], ub = (uint32_t)rb[j], va = (uint32_t)la[j], vb = (uint32_t)lb[j];
+                const uint32_t xe = pr < 4 ? __builtin_amdgcn_perm(ub, ua, 0x05040100u) : (ua & 0xffffu);     // even channel: taps 2p | 2p+1
+                const uint32_t xo = pr < 4 ? __builtin_amdgcn_perm(ub, ua, 0x07060302u) : (ua >> 16);
+                const uint32_t le = pr < 4 ? __builtin_amdgcn_perm(vb, va, 0x05040100u) : (va & 0xffffu);
+                const uint32_t lo_ = pr < 4 ? __builtin_amdgcn_perm(vb, va, 0x07060302u) : (va >> 16);
+                // (the two small products first: each is 2^-11 of the hi x hi one)
+                o[2 * j] = Half16<HT>::dot2(xe, wh[2 * j], Half16<HT>::dot2(xe, wlo[2 * j], Half16<HT>::dot2(le, wh[2 * j], o[2 * j])));
+                o[2 * j + 1] = Half16<HT>::dot2(xo, wh[2 * j + 1], Half16<HT>::dot2(xo, wlo[2 * j + 1], Half16<HT>::dot2(lo_, wh[2 * j + 1], o[2 * j + 1])));
+            }
+        }
+        float ol[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            o[i] = fmaxf(o[i], 0.f);
+            ol[i] = o[i] - (float)(HT)o[i];
+        }
+        const int row = r0 + q * 64;
+        const int sw = (s & 1) * A_STAGE + row * 128 + ((chunk ^ (row & 7)) << 4);
+        Vec8<HT>::store(reinterpret_cast<HT*>(lds + S_LDS_AH + sw), o);
+        Vec8<HT>::store(reinterpret_cast<HT*>(lds + S_LDS_AL + sw), ol);
+    };
+
+    // ---- prologue: parameters and W hi(0) by DMA, slice 0 of both pixels; then pixel 0's taps of slice 1
+    dma_w(0);
+    load_taps(0, 0);
+    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");          // (the 18 tap loads are younger than every DMA above)
+    __syncthreads();                 // parameters of K-steps 0 .. 2 and W hi(0) are in LDS
+    produce_a(0, 0);
+    load_taps(0, 1);
+    produce_a(0, 1);
+    if (nk > 1) load_taps(1, 0);
+
+    // vmcnt: hipcc counts its own (tap) loads; the DMAs are invisible to it, which only ever makes its waits longer.  The DMAs of a
+    // sub-step are issued at its top -- the 18 tap loads that follow are the only younger operations -- and awaited at its end.
+    // (Tried and measured equal or 4 % slower, profiles/r05/dwpw_phase_ablation.log: the two waves of a SIMD running the halves of a
+    //  sub-step in opposite order -- depthwise work first / matrix work first --, in three wave groupings.  Written as a three-slot
+    //  runtime loop that variant also met a hipcc hazard miss: the accumulators rotate through v_mov_b64 copies at the loop latch, and
+    //  the first copy read the last MFMA's result three instructions after its issue, without an s_nop: stale acc[3][3][0:1].)
+    for (int s = 0; s < nk; ++s) {
+        const bool more = s + 1 < nk, more2 = s + 2 < nk;
+        const int ts = (s & 1) * A_STAGE;
+        auto mfma_hi = [&](int kk) {            // weight slice hi (ring slot 0) x lo tile and x hi tile
+            v8 wa[4], ah[4], al[4];
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) wa[nj] = *reinterpret_cast<const v8*>(lds + (kk ? w_sw[1] : w_sw[0]) + nj * 512);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                ah[mi] = *reinterpret_cast<const v8*>(lds + S_LDS_AH + ts + (kk ? a_sw[1] : a_sw[0]) + mi * 2048);
+                al[mi] = *reinterpret_cast<const v8*>(lds + S_LDS_AL + ts + (kk ? a_sw[1] : a_sw[0]) + mi * 2048);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) { if constexpr (!(DW_EXP & 1)) acc[mi][nj] = Half16<HT>::mfma(wa[nj], al[mi], acc[mi][nj]); else if constexpr (!(DW_EXP & 8)) asm volatile("" :: "v"(wa[nj]), "v"(al[mi])); }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) { if constexpr (!(DW_EXP & 1)) acc[mi][nj] = Half16<HT>::mfma(wa[nj], ah[mi], acc[mi][nj]); else if constexpr (!(DW_EXP & 8)) asm volatile("" :: "v"(wa[nj]), "v"(ah[mi])); }
+        };
+        auto mfma_lo = [&](int kk) {            // weight slice lo (ring slot 1) x hi tile
+            v8 wa[4], ah[4];
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) wa[nj] = *reinterpret_cast<const v8*>(lds + W_STAGE + (kk ? w_sw[1] : w_sw[0]) + nj * 512);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) ah[mi] = *reinterpret_cast<const v8*>(lds + S_LDS_AH + ts + (kk ? a_sw[1] : a_sw[0]) + mi * 2048);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) { if constexpr (!(DW_EXP & 1)) acc[mi][nj] = Half16<HT>::mfma(wa[nj], ah[mi], acc[mi][nj]); else if constexpr (!(DW_EXP & 8)) asm volatile("" :: "v"(wa[nj]), "v"(ah[mi])); }
+        };
+        // ---- j = 0: 64 MFMAs; pixel 0 of the depthwise slice s + 1, then the request for pixel 1's taps
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own tile writes are in LDS
+        __builtin_amdgcn_s_barrier();
+        dma_p(s + 3);
+        dma_w(2 * s + 1);
+        mfma_hi(0);
+        __builtin_amdgcn_sched_barrier(0);          // (keeps the next half's fragment reads below the depthwise work: registers)
+        if (more) { produce_a(s + 1, 0); load_taps(s + 1, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_hi(1);
+        if (more) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- j = 1: 32 MFMAs; pixel 1 of the depthwise slice s + 1, then the request for pixel 0's taps of slice s + 2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (more) dma_w(2 * s + 2);
+        mfma_lo(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) { produce_a(s + 1, 1); if (more2) load_taps(s + 2, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_lo(1);
+        if (more2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    // ---- epilogue: ReLU, split, store (bias was the accumulators' start value)
+    // (lane geometry from an opaque copy: hipcc otherwise computes the 64-bit store offsets in front of the K loop and spills them)
+    int elane = lane;
+    asm volatile("" : "+v"(elane));
+    const int efr = elane & 15;
+    const int nbase = nt * TN + wn * 64 + (elane >> 4) * 16;
+    if (nbase + 16 <= p.N) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = mt * TM + wm * 64 + mi * 16 + efr;
+            if (m < ((DW_EXP & 128) ? (acc[mi][0][0] == 12345.f ? 1 : 0) : p.M)) {
+                float lo[8], hi[8];
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        lo[nj * 4 + r] = fmaxf(acc[mi][nj][r], 0.f);
+                        hi[nj * 4 + r] = fmaxf(acc[mi][2 + nj][r], 0.f);
+                    }
+                HT* cp = static_cast<HT*>(p.C) + (long long)m * p.ldc + nbase;
+                Vec8<HT>::store(cp, lo);
+                Vec8<HT>::store(cp + 8, hi);
+                if (p.C_lo) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { lo[i] -= (float)(HT)lo[i]; hi[i] -= (float)(HT)hi[i]; }
+                    HT* cl = static_cast<HT*>(p.C_lo) + (long long)m * p.ldc + nbase;
+                    Vec8<HT>::store(cl, lo);
+                    Vec8<HT>::store(cl + 8, hi);
+                }
+            }
+        }
+    }
+}
+
+int launch_dwpw_xs(const DwPwArgs& a, hipStream_t s) {
+    constexpr int lds_bytes = S_LDS_P + XP_RING * XP_STEP;
+    static_assert(lds_bytes <= 160 * 1024, "k_dwpw_xs LDS");
+    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw_xs), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_dwpw_xs, dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
+    AVL_LAUNCH_CHECK();
+    return AVL_OK;
+}
+
 template <typename HT, int WSUB>
 int launch_dwpw_typed(const DwPwArgs& a, int mtiles, hipStream_t s) {
     const int lds_bytes = LDS_P + (a.K / 64) * P_STEP;
@@ -506,8 +793,9 @@ int validate_dwpw(const avl_seg_op& op) {
     AVL_REQUIRE(is_half(op.dtype), "fused depthwise+pointwise needs a 16-bit activation type");
     AVL_REQUIRE(op.in && op.out && op.weight && op.bias && op.in2, "dwpw has NULL buffers");
     AVL_REQUIRE(!op.w_split || op.dtype == AVL_F16, "split weights need AVL_F16 activations");
-    AVL_REQUIRE(!op.in_lo && !op.in2_lo && (!op.out_lo || op.w_split), "dwpw: only the output may be split, and only with w_split");
-    AVL_REQUIRE(reinterpret_cast<uintptr_t>(op.out_lo) % 16 == 0, "dwpw low plane must be 16-byte aligned");
+    AVL_REQUIRE(!op.in2_lo && (!op.out_lo || op.w_split), "dwpw: the output may be split only with w_split");
+    AVL_REQUIRE(!op.in_lo || op.w_split == 2, "dwpw: a split input (in_lo) needs the exact depthwise stage (w_split 2: k_dwpw_xs)");
+    AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.out_lo) | reinterpret_cast<uintptr_t>(op.in_lo)) % 16 == 0, "dwpw low planes must be 16-byte aligned");
     const int M = op.out_h * op.out_w, K = op.in_c, N = op.out_c;
     AVL_REQUIRE(op.stride == 1 && op.ksize == 3 && op.dil >= 1 && op.pad >= 0 && op.out_h == op.in_h + 2 * op.pad - 2 * op.dil &&
                     op.out_w == op.in_w + 2 * op.pad - 2 * op.dil && M > 0,
@@ -525,7 +813,7 @@ int validate_dwpw(const avl_seg_op& op) {
 
 int launch_dwpw(const avl_seg_op& op, hipStream_t s) {
     DwPwArgs a;
-    a.X = op.in; a.W = op.weight; a.bias = op.bias; a.dwp = static_cast<const uint32_t*>(op.in2); a.C = op.out;
+    a.X = op.in; a.X_lo = op.in_lo; a.W = op.weight; a.bias = op.bias; a.dwp = static_cast<const uint32_t*>(op.in2); a.C = op.out;
     a.H = op.in_h; a.Wd = op.in_w; a.OW = op.out_w; a.ldx = op.in_ld; a.ldc = op.out_ld; a.pad = op.pad;
     a.M = op.out_h * op.out_w; a.N = op.out_c; a.K = op.in_c; a.dil = op.dil;
     a.ntiles = (a.N + TN - 1) / TN;
@@ -535,6 +823,7 @@ int launch_dwpw(const avl_seg_op& op, hipStream_t s) {
     a.per_xcd = (mtiles + 7) / 8;
     a.order = reinterpret_cast<const int*>(a.dwp + (a.K / 64) * ((op.w_split == 2 ? XP_STEP : P_STEP) / 4));
     a.C_lo = op.out_lo;
+    if (op.w_split == 2 && op.in_lo) return launch_dwpw_xs(a, s);        // the same with a split input (the "mixed" decoder, the split16 ASPP)
     if (op.w_split == 2) return launch_dwpw_x(a, s);         // exact depthwise stage: f16 weight pairs, split tile (pack_dw_pairs(split=True))
     if (op.w_split) return launch_dwpw_typed<f16, 2>(a, mtiles, s);
     return op.dtype == AVL_F16 ? launch_dwpw_typed<f16, 1>(a, mtiles, s) : launch_dwpw_typed<bf16, 1>(a, mtiles, s);

@@ -45,9 +45,10 @@ struct GemmArgs {
     long long a_lo_delta;
     const void* R_lo;
     void* C_lo;
-    // k_gemm with out_f32 and N <= 32 (the classifier): torch.argmax over the row's N values (semantic_segmentation.py:56: first maximal
-    // index wins, a NaN counts as maximal) written here as one byte per row, from the very values stored as logits; NULL = not wanted
-    unsigned char* labels;
+    // k_gemm with out_f32 and N <= 32 (the classifier) has no low plane: C_lo is then the uint8 label map, torch.argmax over the row's N
+    // values (semantic_segmentation.py:56: first maximal index wins, a NaN counts as maximal) written as one byte per row from the very
+    // values stored as logits; NULL = not wanted.  (Not a field of its own: MxArgs embeds this struct and k_gemm_mx_pipe keeps every
+    // kernel argument in SGPRs.)
 };
 
 // which sub-steps of a K block bring a NEW activation tile (the others reuse the tile already in LDS)
@@ -178,7 +179,8 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm(GemmArgs p) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + nbase + 4 * j);
         bias[4 * j] = b.x; bias[4 * j + 1] = b.y; bias[4 * j + 2] = b.z; bias[4 * j + 3] = b.w;
     }
-    if (p.labels) {
+    unsigned char* const labels = p.out_f32 ? static_cast<unsigned char*>(p.C_lo) : nullptr;
+    if (labels) {
         // the classifier's arg-max (N <= 32: channel blocks kq = 0 and 1 of a row sit 16 lanes apart), on the values stored below; every lane
         // takes part in the exchange, so this runs in front of the loop whose lanes drop out individually
 #pragma unroll
@@ -194,7 +196,7 @@ __global__ void __launch_bounds__(WM* WN * 64) k_gemm(GemmArgs p) {
             const float ob = __shfl_down(best, 16);
             const int oi = __shfl_down(bi, 16);
             if (nbase + 16 < p.N && (ob > best || (ob != ob && best == best))) { best = ob; bi = oi; }
-            if (kq == 0 && m < p.M) p.labels[m] = (unsigned char)bi;
+            if (kq == 0 && m < p.M) labels[m] = (unsigned char)bi;
         }
     }
 #pragma unroll
@@ -1515,6 +1517,7 @@ int validate_gemm(const avl_seg_op& op) {
     AVL_REQUIRE(op.out_rows >= M, "GEMM writes %d rows, output has %d", M, op.out_rows);
     if (!op.out_f32) AVL_REQUIRE((op.out_ld * es) % 16 == 0 && N % 16 == 0, "GEMM out_ld %d / N %d not 16-aligned", op.out_ld, N);
     if (op.in2) AVL_REQUIRE(op.in2_ld >= N && (op.in2_ld * es) % 16 == 0, "GEMM residual ld %d", op.in2_ld);
+    if (op.out_f32) AVL_REQUIRE(!op.out_lo, "GEMM: an fp32 output has no low plane");
     if (op.out_f32 && op.out_mx)      // the fused arg-max (labels through out_mx): the small-N kernel, plain logits
         AVL_REQUIRE(N <= 32 && !op.in2 && !op.relu && op.w_split != 2 && t.bn == 64 && !ring_eligible(op),
                     "GEMM: an arg-max output (out_f32 with out_mx = uint8 labels[rows]) needs N <= 32, no residual, no ReLU (N %d)", N);
@@ -1569,7 +1572,6 @@ int launch_gemm(const avl_seg_op& op, hipStream_t s) {
     a.lda = op.in_ld; a.ldr = op.in2_ld; a.ldc = op.out_ld;
     a.M = op.out_h * op.out_w; a.N = op.out_c; a.K = op.in_c;
     a.relu = op.relu; a.out_f32 = op.out_f32;
-    a.labels = (op.out_f32 && op.w_split != 2) ? static_cast<unsigned char*>(op.out_mx) : nullptr;      // (out_f32 ops have no MX bundle: out_mx carries the label map)
     if (op.w_split == 2) {
         MxArgs mx;
         memset(&mx, 0, sizeof(mx));
@@ -1623,7 +1625,8 @@ int launch_gemm(const avl_seg_op& op, hipStream_t s) {
     }
     a.nsub = op.w_split ? (op.in_lo ? 3 : 2) : 1;
     a.a_lo_delta = op.in_lo ? static_cast<const char*>(op.in_lo) - static_cast<const char*>(op.in) : 0;
-    a.R_lo = op.in2_lo; a.C_lo = op.out_lo;
+    a.R_lo = op.in2_lo;
+    a.C_lo = op.out_f32 ? op.out_mx : op.out_lo;      // (out_f32 ops have neither a low plane nor an MX bundle: out_mx carries the label map)
     const TileCfg t = pick_tile(op);
     const int mtiles = (a.M + t.bm - 1) / t.bm;
     a.ntiles = (a.N + t.bn - 1) / t.bn;

@@ -500,7 +500,7 @@ class SegNet(object):
     native plan.  ``forward(image_u8_cuda)`` runs it; ``labels`` / ``logits`` are views of its outputs."""
 
     ROW_PAD = 256        # GEMM tiles read whole 128/256-row tiles
-    MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx", "dw_exact", "layer1_lo", "fuse_block", "full_split")    # keyword switches of the "mixed" mode
+    MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx", "dw_exact", "layer1_lo", "fuse_block", "full_split", "fuse_decoder")    # keyword switches of the "mixed" mode
 
     def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8, fuse_dwpw=True, raw_frame=None,
                  part=None, **mixed_opts):
@@ -531,6 +531,7 @@ class SegNet(object):
         self.mixed_mx = self.mixed and mixed_opts.get("mx", True)
         self.mixed_trunk_fp4 = mixed_opts.get("trunk_fp4", True)
         self.mixed_fuse_ds = mixed_opts.get("fuse_ds", True)     # stride-1 downsample folded into conv3 (second input along K)
+        self.mixed_fuse_decoder = mixed_opts.get("fuse_decoder", True)   # the decoder's refine blocks as one k_dwpw_xs launch each (split input)
         self.mixed_dw_exact = mixed_opts.get("dw_exact", True)    # fused depthwise+pointwise (ASPP) with split depthwise weights and a split depthwise result (k_dwpw_x)
         # layer1_lo = False (default): the first two blocks of layer1 write a SINGLE f16 trunk plane (the last one keeps hi + lo: the
         # decoder's low-level branch and layer2 read it).  layer1's GEMMs are HBM-bound (K = 128 / 256 at 129 600 pixels): the lo planes
@@ -552,7 +553,7 @@ class SegNet(object):
         self.act_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "mixed": torch.float16}[precision]
         self.avl_dtype = {"bf16": _lib.AVL_BF16, "f16": _lib.AVL_F16, "f32": _lib.AVL_F32, "mixed": _lib.AVL_F16}[precision]
         self.half = precision != "f32"              # 16-bit activations: MFMA stem / grouped-conv kernels
-        self.fuse_dwpw = bool(fuse_dwpw) and not self.full_split   # ASPP branches: depthwise + pointwise as one kernel (16-bit types); full_split: two kernels (split in, split out; three passes)
+        self.fuse_dwpw = bool(fuse_dwpw)            # ASPP branches / decoder refine blocks: depthwise + pointwise as one kernel (16-bit types)
         self.num_classes = num_classes
         self._keep = []            # every tensor the plan points at
         self._free = {}            # numel -> [tensor] pool of released activation buffers
@@ -741,7 +742,9 @@ class SegNet(object):
         self._keep.append(params)
         ip, ild, irows = self._view(src)
         op_, old, orows = self._view(dst, dst_col)
-        self._op(name, OP_DWPW, in_=ip, in2=params.data_ptr(), out=op_, weight=wdev.data_ptr(), bias=bdev.data_ptr(), in_h=h, in_w=wd,
+        # a split input (hi + lo planes) goes through k_dwpw_xs, which exists with the exact depthwise stage only
+        in_lo = self._lo(src) if exact else 0
+        self._op(name, OP_DWPW, in_=ip, in_lo=in_lo, in2=params.data_ptr(), out=op_, weight=wdev.data_ptr(), bias=bdev.data_ptr(), in_h=h, in_w=wd,
                  in_c=cin, in_ld=ild, in_rows=irows, out_h=oh, out_w=ow, out_c=cout, out_ld=old, out_rows=orows, relu=1, w_rows=w_rows,
                  ksize=3, stride=1, pad=padding, dil=dilation, groups=cin, w_split=(2 if exact else int(self.mixed)),
                  out_lo=self._lo(dst, dst_col) if self.mixed else 0)
@@ -1041,10 +1044,11 @@ class SegNet(object):
             w, b = fold_bn(st, p + ".depthwise_cnn.conv.weight", p + ".depthwise_cnn.bn")
             w2, b2 = fold_bn(st, p + ".pointwise_cnn.conv.weight", p + ".pointwise_cnn.bn")
             y = self._act(ohw[0] * ohw[1], w2.shape[0], split=self.mixed)
-            # "mixed": the decoder keeps every activation as hi + lo and its depthwise weights in fp32 (the logits are most
-            # sensitive to roundings here: tools/precision_study.py), so the two kernels stay separate (split depthwise
-            # kernel -> three-pass GEMM)
-            if self.half and self.fuse_dwpw and cin % 64 == 0 and cin <= 2048 and not self.mixed:
+            # "mixed": the decoder keeps every activation as hi + lo (the logits are most sensitive to roundings here:
+            # tools/precision_study.py).  fuse_decoder (default): one k_dwpw_xs launch per block -- split input, depthwise weights as
+            # f16 pairs, the depthwise result as a split tile in LDS, three MFMA passes, split output; off: the split depthwise
+            # kernel (fp32 weights) -> HBM -> an MX / three-pass GEMM
+            if self.half and self.fuse_dwpw and cin % 64 == 0 and cin <= 2048 and (not self.mixed or (self.mixed_fuse_decoder and self.mixed_dw_exact)):
                 self._dwpw(p, x, hw, cin, w, b, w2, b2, y, 0, 1, padding=0)
                 self._release(x)
             else:
