@@ -6,7 +6,8 @@ CS=vision_semantic_segmentation_amd/csrc
 if [ "$1" = "build" ]; then
   shift
   for v in "$@"; do
-    make -s -C $CS -j6 OUT=$PWD/vision_semantic_segmentation_amd/libavl_hip_dw$v.so BUILD=build_dw$v EXPFLAGS=-DDW_EXP=$v
+    # (a variant "N_M" also defines DW_IL=M)
+    make -s -C $CS -j6 OUT=$PWD/vision_semantic_segmentation_amd/libavl_hip_dw$v.so BUILD=build_dw$v EXPFLAGS="-DDW_EXP=${v%%_*} -DDW_IL=$( [ "${v#*_}" != "$v" ] && echo ${v#*_} || echo 4 )"
   done
   exit 0
 fi

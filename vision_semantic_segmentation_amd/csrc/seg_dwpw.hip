@@ -677,7 +677,9 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
     // (Tried and measured equal or 4 % slower, profiles/r05/dwpw_phase_ablation.log: the two waves of a SIMD running the halves of a
     //  sub-step in opposite order -- depthwise work first / matrix work first --, in three wave groupings.  Written as a three-slot
     //  runtime loop that variant also met a hipcc hazard miss: the accumulators rotate through v_mov_b64 copies at the loop latch, and
-    //  the first copy read the last MFMA's result three instructions after its issue, without an s_nop: stale acc[3][3][0:1].)
+    //  the first copy read the last MFMA's result three instructions after its issue, without an s_nop: stale acc[3][3][0:1].
+    //  Also tried: the depthwise VALU work in the MFMAs' issue shadows -- one scheduling region per sub-step with
+    //  sched_group_barrier(MFMA 1 : VALU 4 / 6 / 8): +1..+4 % time.)
     for (int s = 0; s < nk; ++s) {
         const bool more = s + 1 < nk, more2 = s + 2 < nk;
         const int ts = (s & 1) * A_STAGE;
