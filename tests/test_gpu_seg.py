@@ -54,6 +54,30 @@ def test_f32_logits_within_1e3_of_oracle(state, hw, cuda_device):
     assert agree >= 0.999
 
 
+@pytest.mark.parametrize("hw", [(97, 131), (66, 70)])
+def test_image_sizes_that_are_no_multiple_of_anything(state, hw, cuda_device):
+    """The reference takes any image (semantic_segmentation.py:41-57: no size check; torchvision's conv arithmetic floors).  Sizes whose
+    stem / pool / layer2 outputs are odd and whose rows are no multiple of any tile: f32, mixed and the split16 plan against the oracle
+    (more sizes, 250 x 333 ... 375 x 1242: tools/micro/odd_sizes.py, profiles/r05/odd_sizes.log)."""
+    import torch
+    from oracle import network_oracle as no
+    from vision_semantic_segmentation_amd.network import SegNet
+    h, w = hw
+    img = np.random.default_rng(h).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    ref = no.forward_logits(state, img)[0]
+    h4, w4 = ((h - 1) // 2 + 1 - 1) // 2 + 1, ((w - 1) // 2 + 1 - 1) // 2 + 1
+    assert tuple(ref.shape) == (19, h4 - 4, w4 - 4)
+    for precision, opts, bar in (("f32", {}, 1e-5), ("mixed", {}, 1e-3), ("mixed", dict(full_split=True), 1e-4)):
+        net = SegNet(state, h, w, precision=precision, device=cuda_device, **opts)
+        net.forward(torch.from_numpy(img).to(cuda_device))
+        got = net.logits.permute(2, 0, 1).float().cpu()
+        assert got.shape == ref.shape
+        err = float((got - ref).abs().max() / ref.abs().max())
+        print("%d x %d %s %s: %.2e of max|logit|" % (h, w, precision, opts, err))
+        assert err <= bar, (precision, opts, err)
+        assert np.array_equal(net.labels.cpu().numpy(), got.argmax(0).numpy())
+
+
 @pytest.mark.parametrize("precision,bar", [("f32", 1e-4), ("mixed", 1e-3), ("split16", 1e-4)])
 def test_output_stride_16(state, precision, bar, cuda_device):
     """MODEL.OUTPUT_STRIDE = 16 (deeplab_v3_plus.py:30-36: ASPP dilations 1, 6, 12, 18; backbone/build.py:11-16: only layer4 trades its stride
