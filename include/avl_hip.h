@@ -245,7 +245,11 @@ int avl_eval_map(const uint8_t* color_map, int H, int W, const uint8_t* mask, in
                                 w_split = 2 (AVL_F16): the EXACT depthwise stage -- depthwise weights as f16 pairs hi + lo
                                 and a split depthwise result; in2 = [K/64][8][11][8] dwords per 8-channel chunk: five
                                 tap pairs of the hi parts, five of the lo parts, the fp32 bias; then the tile order as
-                                above.  `weight` is the 1x1 conv's [n][K/64][hi 64 | lo 64] as for w_split = 1. */
+                                above.  `weight` is the 1x1 conv's [n][K/64][hi 64 | lo 64] as for w_split = 1.
+                                With in_lo (w_split = 2 only): the input is two f16 planes (the "mixed" decoder's refine blocks,
+                                decoder.py:33-43; the ASPP branches of the complete hi + lo plan).  w_layout = 1 (with in_lo):
+                                a tile is an 8 x 16 block of output pixels instead of 128 consecutive ones; the order array
+                                then has ceil(out_h / 8) * ceil(out_w / 16) entries (tile = block row * ceil(out_w / 16) + block column). */
 
 #define AVL_OP_BOTTLENECK 12 /* one torchvision Bottleneck of layer1 (backbone/resnet.py:24-43; stride 1, dilation 1, width 128 -> 256
                                 channels) in ONE kernel, AVL_F16 "mixed" precision: conv1 1x1 +b+ReLU -> grouped 3x3 (32 groups, pad 1)
@@ -277,7 +281,8 @@ typedef struct avl_seg_op {
                                 uint8 labels[out_rows] and the epilogue also writes torch.argmax over each row's N logits there (first maximal
                                 index wins, a NaN counts as maximal; semantic_segmentation.py:56) -- AVL_OP_ARGMAX without its launch */
     int32_t w_rows;          /* GEMM: rows of `weight` allocated (out_c padded to the N tile)   */
-    int32_t w_layout;        /* GCONV: 0 = float [group][tap][ci][co] (direct kernel),
+    int32_t w_layout;        /* DWPW:  0 = tiles of 128 consecutive pixels, 1 = 8 x 16-pixel blocks (split input only, see AVL_OP_DWPW)
+                                GCONV: 0 = float [group][tap][ci][co] (direct kernel),
                                        1 = bf16 block-diagonal 32-channel windows [window][2][9][16][32] (MFMA kernel)
                                 STEM:  0 = float [7][7][3][64] (direct kernel), 1 = bf16 [4][6][16][32] (MFMA kernel)
                                 GEMM:  0 = the library picks the kernel; 1 .. 4 force one tile configuration of the 16-bit

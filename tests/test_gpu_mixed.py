@@ -231,18 +231,21 @@ def test_exact_fused_depthwise_pointwise(case, cuda_device):
     assert torch.all(out[:, M:] == 7.0)
 
 
-@pytest.mark.parametrize("case", [(37, 53, 512, 256, 1, 0), (20, 31, 256, 256, 1, 0), (30, 40, 1024, 256, 12, 12), (16, 16, 64, 512, 1, 1), (9, 140, 128, 64, 2, 0)])
+@pytest.mark.parametrize("case", [(37, 53, 512, 256, 1, 0, 0), (37, 53, 512, 256, 1, 0, 1), (20, 31, 256, 256, 1, 0, 1), (30, 40, 1024, 256, 12, 12, 0), (16, 16, 64, 512, 1, 1, 0),
+                                  (16, 16, 64, 512, 1, 1, 1), (9, 140, 128, 64, 2, 0, 0), (11, 70, 128, 64, 1, 0, 1)])
 def test_exact_fused_depthwise_pointwise_with_a_split_input(case, cuda_device):
     """round 5: AVL_OP_DWPW with w_split = 2 AND in_lo (k_dwpw_xs: the mixed decoder's refine blocks decoder.py:33-43 -- pad 0 --, the
     split16 plan's ASPP branches): input hi + lo planes, (xh + xl)(wh + wl) without the lo x lo term (2^-22), everything else as
-    k_dwpw_x -- against a float64 evaluation of the same operands.  Cases: the decoder's two shapes, a dilated padded branch, two
-    output-channel tiles, a tile spanning several image rows with K = 2 steps."""
+    k_dwpw_x -- against a float64 evaluation of the same operands.  Cases (last number: w_layout, 1 = 8 x 16-pixel tiles as the decoder
+    uses them, block counts that do not divide the output): the decoder's two shapes, a dilated padded branch, two output-channel
+    tiles, a tile spanning several image rows with K = 2 steps."""
     import torch
     import torch.nn.functional as F
     from test_gpu_ops import _from_rows, _nhwc_rows
     from vision_semantic_segmentation_amd import _lib
-    from vision_semantic_segmentation_amd.network import OP_DWPW, AvlSegOp, dwpw_tile_order, pack_dw_pairs_split, pack_split_rows, split_f16
-    H, W, K, N, d, pad = case
+    from vision_semantic_segmentation_amd.network import (OP_DWPW, AvlSegOp, dwpw_block_order, dwpw_tile_order, pack_dw_pairs_split, pack_split_rows,
+                                                          split_f16)
+    H, W, K, N, d, pad, blocks = case
     OH, OW = H + 2 * pad - 2 * d, W + 2 * pad - 2 * d
     g = torch.Generator().manual_seed(H * 31 + W + K + d + 7)
     x = torch.randn((1, K, H, W), generator=g, dtype=torch.float64)
@@ -260,11 +263,11 @@ def test_exact_fused_depthwise_pointwise_with_a_split_input(case, cuda_device):
     b2p[:N] = b2
     w2d, b2d = pack_split_rows(w2p, 2).to(cuda_device), b2p.to(cuda_device)
     out = torch.full((2, Mp, N), 7.0, dtype=torch.float16, device=cuda_device)
-    params = torch.cat([pack_dw_pairs_split(w1, b1), dwpw_tile_order(OH, OW, d)]).to(cuda_device)
+    params = torch.cat([pack_dw_pairs_split(w1, b1), dwpw_block_order(OH, OW) if blocks else dwpw_tile_order(OH, OW, d)]).to(cuda_device)
     op = AvlSegOp()
     op.kind, op.dtype = OP_DWPW, _lib.AVL_F16
     op.in_, op.in_lo, op.in2, op.out, op.out_lo = src[0].data_ptr(), src[1].data_ptr(), params.data_ptr(), out[0].data_ptr(), out[1].data_ptr()
-    op.weight, op.bias, op.w_split = w2d.data_ptr(), b2d.data_ptr(), 2
+    op.weight, op.bias, op.w_split, op.w_layout = w2d.data_ptr(), b2d.data_ptr(), 2, blocks
     op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = H, W, K, K, src.shape[1]
     op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = OH, OW, N, N, Mp
     op.relu, op.w_rows, op.ksize, op.stride, op.pad, op.dil, op.groups = 1, Np, 3, 1, pad, d, K

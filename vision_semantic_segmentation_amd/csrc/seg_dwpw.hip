@@ -36,6 +36,7 @@ constexpr int P_STEP = 8 * 6 * 8 * 4;                                         //
 struct DwPwArgs {
     const void* X;
     const void* X_lo;        // k_dwpw_xs: low plane of the input (same row stride), else NULL
+    int tiles_x;             // k_dwpw_xs: > 0 = the 128 pixels of a tile are an 8 x 16 block (tile mt = (mt / tiles_x, mt % tiles_x)) instead of 128 consecutive pixels
     const void* W;
     const float* bias;
     const uint32_t* dwp;     // [K/64][chunk 8][6][8] dwords: 5 tap pairs (lo = tap 2p, hi = tap 2p+1, 16-bit type) + fp32 bias
@@ -548,16 +549,29 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
     const int chunk = tid & 7, r0 = tid >> 3;
     int vbase[2];
     unsigned vmask[2];
+    // 8 x 16 blocks (tiles_x > 0; stride-1 taps): a tile's taps fall on 10 x 18 input pixels instead of 3 x 130 -- the row-segment form
+    // fetched its input 3x from HBM (PMC: 585 MB per launch against 198 MB of input, L2 hit 0.52)
+    const int tty = p.tiles_x > 0 ? mt / p.tiles_x : 0, ttx = p.tiles_x > 0 ? mt - tty * p.tiles_x : 0;
+    const int OHt = p.M / p.OW;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int m = mt * TM + r0 + q * 64;
-        const int y = m / p.OW, x = m - y * p.OW;
+        const int ml = r0 + q * 64;
+        int y, x;
+        bool live;
+        if (p.tiles_x > 0) {
+            y = tty * 8 + (ml >> 4); x = ttx * 16 + (ml & 15);
+            live = (y < OHt) & (x < p.OW);
+        } else {
+            const int m = mt * TM + ml;
+            y = m / p.OW; x = m - y * p.OW;
+            live = m < p.M;
+        }
         vbase[q] = (int)((((long long)(y - p.pad) * p.Wd + (x - p.pad)) * p.ldx + chunk * 8) * 2);
         unsigned mk = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int iy = y - p.pad + (t / 3) * p.dil, ix = x - p.pad + (t % 3) * p.dil;
-            mk |= (unsigned)((m < p.M) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd)) << t;
+            mk |= (unsigned)(live & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd)) << t;
         }
         vmask[q] = mk;
     }
@@ -746,7 +760,11 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
     if (nbase + 16 <= p.N) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-            const int m = mt * TM + wm * 64 + mi * 16 + efr;
+            int m = mt * TM + wm * 64 + mi * 16 + efr;
+            if (p.tiles_x > 0) {           // row wm * 64 + mi * 16 + efr of the tile = block row wm * 4 + mi, column efr
+                const int y = tty * 8 + wm * 4 + mi, x = ttx * 16 + efr;
+                m = ((y < OHt) & (x < p.OW)) ? y * p.OW + x : p.M;
+            }
             if (m < ((DW_EXP & 128) ? (acc[mi][0][0] == 12345.f ? 1 : 0) : p.M)) {
                 float lo[8], hi[8];
 #pragma unroll
@@ -797,6 +815,7 @@ int validate_dwpw(const avl_seg_op& op) {
     AVL_REQUIRE(!op.w_split || op.dtype == AVL_F16, "split weights need AVL_F16 activations");
     AVL_REQUIRE(!op.in2_lo && (!op.out_lo || op.w_split), "dwpw: the output may be split only with w_split");
     AVL_REQUIRE(!op.in_lo || op.w_split == 2, "dwpw: a split input (in_lo) needs the exact depthwise stage (w_split 2: k_dwpw_xs)");
+    AVL_REQUIRE(op.w_layout == 0 || (op.w_layout == 1 && op.in_lo && op.w_split == 2), "dwpw: w_layout 1 (8 x 16-pixel tiles) exists for the split-input kernel only");
     AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.out_lo) | reinterpret_cast<uintptr_t>(op.in_lo)) % 16 == 0, "dwpw low planes must be 16-byte aligned");
     const int M = op.out_h * op.out_w, K = op.in_c, N = op.out_c;
     AVL_REQUIRE(op.stride == 1 && op.ksize == 3 && op.dil >= 1 && op.pad >= 0 && op.out_h == op.in_h + 2 * op.pad - 2 * op.dil &&
@@ -815,12 +834,13 @@ int validate_dwpw(const avl_seg_op& op) {
 
 int launch_dwpw(const avl_seg_op& op, hipStream_t s) {
     DwPwArgs a;
-    a.X = op.in; a.X_lo = op.in_lo; a.W = op.weight; a.bias = op.bias; a.dwp = static_cast<const uint32_t*>(op.in2); a.C = op.out;
+    a.X = op.in; a.X_lo = op.in_lo; a.W = op.weight;
+    a.tiles_x = (op.w_layout == 1) ? (op.out_w + 15) / 16 : 0; a.bias = op.bias; a.dwp = static_cast<const uint32_t*>(op.in2); a.C = op.out;
     a.H = op.in_h; a.Wd = op.in_w; a.OW = op.out_w; a.ldx = op.in_ld; a.ldc = op.out_ld; a.pad = op.pad;
     a.M = op.out_h * op.out_w; a.N = op.out_c; a.K = op.in_c; a.dil = op.dil;
     a.ntiles = (a.N + TN - 1) / TN;
     a.x_bytes = (unsigned)((long long)op.in_rows * op.in_ld * 2);
-    const int mtiles = (a.M + TM - 1) / TM;
+    const int mtiles = a.tiles_x > 0 ? a.tiles_x * ((op.out_h + 7) / 8) : (a.M + TM - 1) / TM;     // (the host's visiting order in2 has this many entries)
     a.mtiles = mtiles;
     a.per_xcd = (mtiles + 7) / 8;
     a.order = reinterpret_cast<const int*>(a.dwp + (a.K / 64) * ((op.w_split == 2 ? XP_STEP : P_STEP) / 4));

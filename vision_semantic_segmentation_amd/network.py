@@ -301,6 +301,15 @@ def dwpw_tile_order(h, w, dilation, tile=128):
     return torch.tensor(keys, dtype=torch.int32)
 
 
+def dwpw_block_order(h, w, band=4):
+    """Visiting order of the 8 x 16-pixel tiles of AVL_OP_DWPW with w_layout = 1 (stride-1 taps: the decoder's refine blocks): bands
+    of `band` block rows, walked column by column, so that the ~32 tiles an XCD has in flight form a 4 x 8 patch whose
+    neighbours share their one-pixel halo in that XCD's L2 in both directions."""
+    ty, tx = (h + 7) // 8, (w + 15) // 16
+    order = [r * tx + c for b in range(0, ty, band) for c in range(tx) for r in range(b, min(b + band, ty))]
+    return torch.tensor(order, dtype=torch.int32)
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -738,15 +747,17 @@ class SegNet(object):
         bdev = self._dev(bp, torch.float32)
         exact = self.mixed and self.mixed_dw_exact
         dwp = pack_dw_pairs_split(w_dw, b_dw) if exact else pack_dw_pairs(w_dw, b_dw, self.act_dtype)
-        params = torch.cat([dwp, dwpw_tile_order(oh, ow, dilation)]).to(self.device)
+        # a split input (hi + lo planes) goes through k_dwpw_xs, which exists with the exact depthwise stage only; its stride-1 form
+        # (the decoder) walks 8 x 16-pixel blocks
+        in_lo = self._lo(src) if exact else 0
+        blocks = bool(in_lo) and dilation == 1
+        params = torch.cat([dwp, dwpw_block_order(oh, ow) if blocks else dwpw_tile_order(oh, ow, dilation)]).to(self.device)
         self._keep.append(params)
         ip, ild, irows = self._view(src)
         op_, old, orows = self._view(dst, dst_col)
-        # a split input (hi + lo planes) goes through k_dwpw_xs, which exists with the exact depthwise stage only
-        in_lo = self._lo(src) if exact else 0
         self._op(name, OP_DWPW, in_=ip, in_lo=in_lo, in2=params.data_ptr(), out=op_, weight=wdev.data_ptr(), bias=bdev.data_ptr(), in_h=h, in_w=wd,
                  in_c=cin, in_ld=ild, in_rows=irows, out_h=oh, out_w=ow, out_c=cout, out_ld=old, out_rows=orows, relu=1, w_rows=w_rows,
-                 ksize=3, stride=1, pad=padding, dil=dilation, groups=cin, w_split=(2 if exact else int(self.mixed)),
+                 ksize=3, stride=1, pad=padding, dil=dilation, groups=cin, w_split=(2 if exact else int(self.mixed)), w_layout=int(blocks),
                  out_lo=self._lo(dst, dst_col) if self.mixed else 0)
 
     def _spatial(self, name, kind, src, in_hw, cin, dst, out_hw, cout, weight=None, bias=None, dst_col=0, **extra):
