@@ -198,3 +198,21 @@ def test_bottleneck_weights_are_packed_in_mfma_fragment_order():
     P3d = p3d.reshape(8, 6, 2, 2, 64, 8)
     assert P3d[6, 5, 1, 0, 45, 3] == wd[32 * 6 + (13 >> 2) * 8 + 4 + (13 & 3), 32 + 8 * 2 + 3].to(torch.float16)
     assert torch.equal(P3d[:, :4], P3)
+
+
+def test_fused_depthwise_tile_orders_are_permutations():
+    """AVL_OP_DWPW's visiting orders (include/avl_hip.h): every tile exactly once -- the kernel indexes the array with its slot number and
+    trusts what it reads.  Row tiles: 128 consecutive pixels, tiles a dilation of rows apart adjacent; block tiles (w_layout 1, the decoder):
+    8 x 16 pixels, bands of four block rows walked column by column."""
+    from vision_semantic_segmentation_amd.network import dwpw_block_order, dwpw_tile_order
+    for h, w, d in ((135, 240, 12), (135, 240, 36), (45, 80, 24), (7, 9, 1)):
+        o = dwpw_tile_order(h, w, d).tolist()
+        assert sorted(o) == list(range((h * w + 127) // 128))
+    for h, w in ((268, 478), (266, 476), (9, 17), (8, 16), (1, 1)):
+        o = dwpw_block_order(h, w).tolist()
+        ty, tx = (h + 7) // 8, (w + 15) // 16
+        assert sorted(o) == list(range(ty * tx))
+        # the first 4 * 8 entries form a 4 x 8 patch of blocks (what one XCD's 32 CUs hold at a time)
+        if ty >= 4 and tx >= 8:
+            patch = {(t // tx, t % tx) for t in o[:32]}
+            assert patch == {(r, c) for r in range(4) for c in range(8)}
