@@ -118,7 +118,7 @@ def test_release_library_reads_no_environment_and_holds_no_experiment_kernels():
     assert "getenv" not in undefined
     strings = subprocess.run(["strings", SO], capture_output=True, text=True, check=True).stdout
     for name in ("AVL_MX_PROBE", "AVL_GEMM_PROBE", "AVL_SWEEP_EXP", "AVL_GC_PROBE", "AVL_MX_PIPE", "AVL_MX_LATE", "AVL_MX_TILE",
-                 "AVL_MX_STAGGER", "AVL_APPLY_MODE", "AVL_MASK_MODE", "AVL_GCONV_TH", "AVL_GC_DEPHASE", "AVL_DW_NCHUNK", "AVL_GEMM_DEEP",
+                 "AVL_MX_STAGGER", "AVL_APPLY_MODE", "AVL_MASK_MODE", "AVL_GCONV_TH", "AVL_GC_DEPHASE", "AVL_GC_WALK", "AVL_DW_NCHUNK", "AVL_GEMM_DEEP",
                  "AVL_MX_SPREAD", "AVL_MX_PP", "AVL_MX_GRID", "AVL_SWEEP_VEC", "AVL_MX_SAMETILE", "AVL_BN_PROBE"):
         assert name not in strings, name
     names = list(kn.kernel_notes(SO))

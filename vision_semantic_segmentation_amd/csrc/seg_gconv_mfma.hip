@@ -39,6 +39,9 @@ struct GconvArgs {
     int tiles_x, tiles_y, cchunks;
     int comb;            // 1: stride 1, dilation d > 1 -> tiles live on the d x d residue-class grids (see below)
     int nsp, nslots;     // pixel tiles (all residue classes), and how many of them are in flight (workgroups per channel chunk)
+    int walk;            // 1: a workgroup takes a contiguous run of tiles, numbered DOWN the columns of the tile grid: its next tile is the one
+                         // below, whose top halo rows are this tile's last input rows and still sit in L2 (4-row tiles read 6 rows: without this
+                         // a third of every tile's input came from HBM a second time); 0: tiles slot, slot + nslots, ... numbered along the rows
     int tile_bytes;      // one LDS tile buffer
     int tw_magic;        // ceil(65536 / input tile width): pix / in_tw == (pix * tw_magic) >> 16 for every pixel of a tile
     // WS = 2 (MX variant, see below): FP4 copies of the weights and of the input
@@ -111,8 +114,9 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
     const char* const xs0 = p.xs[0];
     const long long xq_delta = has_lo ? p.xq[1] - p.xq[0] : 0, xs_delta = has_lo ? p.xs[1] - p.xs[0] : 0;
     auto stage = [&](int sp, int buf) -> unsigned {
-        const int tx = sp % p.tiles_x, r1 = sp / p.tiles_x;
-        const int ty = r1 % p.tiles_y, cmb = r1 / p.tiles_y;
+        int tx, ty, cmb;
+        if (p.walk) { ty = sp % p.tiles_y; const int r1 = sp / p.tiles_y; tx = r1 % p.tiles_x; cmb = r1 / p.tiles_x; }
+        else { tx = sp % p.tiles_x; const int r1 = sp / p.tiles_x; ty = r1 % p.tiles_y; cmb = r1 / p.tiles_y; }
         const int ry = p.comb ? cmb / p.dil : 0, rx = p.comb ? cmb % p.dil : 0;
         const int iy0 = ry + (ty * p.th * s - d) * step, ix0 = rx + (tx * TW * s - d) * step;
         const int prow = lane >> 3, cphys = lane & 7;
@@ -162,8 +166,10 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
         }
         return oob;
     };
-    int sp = slot, buf = 0;
-    unsigned oob = sp < p.nsp ? stage(sp, 0) : 0u;
+    const int per = (p.nsp + p.nslots - 1) / p.nslots;
+    const int sp_step = p.walk ? 1 : p.nslots, sp_end = p.walk ? min(p.nsp, (slot + 1) * per) : p.nsp;
+    int sp = p.walk ? slot * per : slot, buf = 0;
+    unsigned oob = sp < sp_end ? stage(sp, 0) : 0u;
 
     // ---- this wave's window and its weight fragments (registers for ALL of the workgroup's tiles)
     const int win = wave & 1;                  // window inside the 64-channel chunk
@@ -259,7 +265,7 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
         return t;
     };
-    for (; sp < p.nsp; sp += p.nslots, buf ^= 1) {
+    for (; sp < sp_end; sp += sp_step, buf ^= 1) {
         unsigned long long t0 = 0, t1 = 0;
         if (kStamps && p.dbg) t0 = stamp();
         // The two waves of a SIMD (w and w + 4) stage the next tile at DIFFERENT points: waves 0-3 in front of their MFMA phase,
@@ -267,13 +273,13 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
         // address), so one wave of the SIMD computes addresses while the other one's MFMAs run.
         const bool late_stage = NJ >= 2 && wave >= 4 && p.dephase;
         oob = 0u;
-        if (!late_stage && sp + p.nslots < p.nsp) oob = stage(sp + p.nslots, buf ^ 1);
+        if (!late_stage && sp + sp_step < sp_end) oob = stage(sp + sp_step, buf ^ 1);
         if (kStamps && p.dbg) { t1 = stamp(); tsum[0] += t1 - t0; t0 = t1; }
         const char* tile = lds + buf * p.tile_bytes;
         f32x4 acc[NJ][2];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            if (NJ >= 2 && j == NJ / 2 && late_stage && sp + p.nslots < p.nsp) oob = stage(sp + p.nslots, buf ^ 1);
+            if (NJ >= 2 && j == NJ / 2 && late_stage && sp + sp_step < sp_end) oob = stage(sp + sp_step, buf ^ 1);
             // all nine tap fragments are requested before the first MFMA: the LDS latency is paid once per sub-tile
             v8 a[9];
             if constexpr (HOIST) {
@@ -369,8 +375,9 @@ __global__ void __launch_bounds__(512) k_gconv_mfma(GconvArgs<HT> p) {
         zero_oob(oob, buf ^ 1);
         if (kStamps && p.dbg) { t1 = stamp(); tsum[2] += t1 - t0; t0 = t1; }
 
-        const int tx = sp % p.tiles_x, r1 = sp / p.tiles_x;
-        const int ty = r1 % p.tiles_y, cmb = r1 / p.tiles_y;
+        int tx, ty, cmb;
+        if (p.walk) { ty = sp % p.tiles_y; const int r1 = sp / p.tiles_y; tx = r1 % p.tiles_x; cmb = r1 / p.tiles_x; }
+        else { tx = sp % p.tiles_x; const int r1 = sp / p.tiles_x; ty = r1 % p.tiles_y; cmb = r1 / p.tiles_y; }
         const int ry = p.comb ? cmb / p.dil : 0, rx = p.comb ? cmb % p.dil : 0;
         const int oy0 = ty * p.th, ox0 = tx * TW;    // tile origin on its grid
 #pragma unroll
@@ -565,6 +572,7 @@ int launch_gconv_typed(const avl_seg_op& op, hipStream_t s) {
         hipLaunchKernelGGL((k_gconv_mfma<HT, WS, NJ, XS>), dim3(a.nslots * a.cchunks), dim3(512), 2 * a.tile_bytes, s, a);             \
     } while (0)
     a.dephase = AVL_EXP_INT("AVL_GC_DEPHASE", 1);
+    a.walk = AVL_EXP_INT("AVL_GC_WALK", 1);
     a.dbg = nullptr;
 #ifdef AVL_EXPERIMENTS
     // timing experiment: where do a wave's cycles go (s_memtime stamps; synchronises the stream: never inside a graph capture)
