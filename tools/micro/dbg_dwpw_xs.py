@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..",
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", "tests")))
 from test_gpu_ops import _from_rows, _nhwc_rows, _run_plan
 from vision_semantic_segmentation_amd import _lib
-from vision_semantic_segmentation_amd.network import OP_DWPW, AvlSegOp, dwpw_tile_order, pack_dw_pairs_split, pack_split_rows, split_f16
+from vision_semantic_segmentation_amd.network import OP_DWPW, AvlSegOp, dwpw_tile_order, pack_dw_f32, pack_dw_pairs_split, pack_split_rows, split_f16
+WS = int(os.environ.get('WS', '3'))
 dev = torch.device("cuda:0")
 H, W, K, N, d, pad = [int(v) for v in sys.argv[1:7]] if len(sys.argv) > 6 else (16, 16, 64, 256, 1, 1)
 OH, OW = H + 2 * pad - 2 * d, W + 2 * pad - 2 * d
@@ -24,17 +25,17 @@ w2p = torch.zeros((Np, K), dtype=torch.float64); w2p[:N] = w2
 b2p = torch.zeros(Np); b2p[:N] = b2
 w2d, b2d = pack_split_rows(w2p, 2).to(dev), b2p.to(dev)
 out = torch.full((2, Mp, N), 7.0, dtype=torch.float16, device=dev)
-params = torch.cat([pack_dw_pairs_split(w1, b1), dwpw_tile_order(OH, OW, d)]).to(dev)
+params = torch.cat([pack_dw_f32(w1, b1) if WS == 3 else pack_dw_pairs_split(w1, b1), dwpw_tile_order(OH, OW, d)]).to(dev)
 op = AvlSegOp()
 op.kind, op.dtype = OP_DWPW, _lib.AVL_F16
 op.in_, op.in_lo, op.in2, op.out, op.out_lo = src[0].data_ptr(), src[1].data_ptr(), params.data_ptr(), out[0].data_ptr(), out[1].data_ptr()
-op.weight, op.bias, op.w_split = w2d.data_ptr(), b2d.data_ptr(), 2
+op.weight, op.bias, op.w_split = w2d.data_ptr(), b2d.data_ptr(), WS
 op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = H, W, K, K, src.shape[1]
 op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = OH, OW, N, N, Mp
 op.relu, op.w_rows, op.ksize, op.stride, op.pad, op.dil, op.groups = 1, Np, 3, 1, pad, d, K
 _run_plan([op])
 w1h, w1l = split_f16(w1.reshape(K, 9))
-w1s = (w1h.double() + w1l.double()).reshape(K, 1, 3, 3)
+w1s = (w1h.double() + w1l.double()).reshape(K, 1, 3, 3) if WS == 2 else w1.float().double()
 a64 = F.relu(F.conv2d(xh.double() + xl.double(), w1s, b1.float().double(), padding=pad, dilation=d, groups=K))
 ref = F.relu(F.conv2d(a64, w2.view(N, K, 1, 1), b2.double()))
 got = _from_rows(out[0].cpu().double() + out[1].cpu().double(), OH, OW, N)

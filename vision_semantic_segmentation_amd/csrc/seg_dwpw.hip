@@ -272,8 +272,13 @@ __global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
 constexpr int X_LDS_W = 0, X_LDS_AH = 2 * W_STAGE, X_LDS_AL = X_LDS_AH + 2 * A_STAGE, X_LDS_P = X_LDS_AL + A_STAGE;
 constexpr int XP_STEP = 8 * 11 * 8 * 4;             // 2816 bytes of depthwise parameters per K-step
 constexpr int XP_RING = 4;
+constexpr int FP_STEP = 8 * 10 * 8 * 4;              // F32W (w_split = 3): fp32 depthwise weights, [K/64][chunk 8][row 10][8]: rows 0 .. 8 = the taps, row 9 = the bias: 2560 bytes
 
+// F32W: one v_fma_mix_f32 per tap and channel (f16 operand by op_sel, fp32 weight and sum) instead of tap-pair permutes + two v_dot2c (hi / lo weight parts):
+// 72 vector instructions per pixel chunk instead of 120, at a cheaper issue rate (tools/micro/overlap.hip), exact weights.
+template <bool F32W>
 __global__ void __launch_bounds__(512) k_dwpw_x(DwPwArgs p) {
+    constexpr int PSTEP = F32W ? FP_STEP : XP_STEP;          // bytes of depthwise parameters per K-step
     typedef f16 HT;
     typedef typename Half16<HT>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -289,8 +294,8 @@ __global__ void __launch_bounds__(512) k_dwpw_x(DwPwArgs p) {
     // ---- depthwise parameters: K-step s -> ring slot s & 3, 176 lanes x 16 bytes
     const uint4* psrc = reinterpret_cast<const uint4*>(p.dwp);
     uint4 pnext = make_uint4(0u, 0u, 0u, 0u);
-    auto load_p = [&](int s) { if (tid < XP_STEP / 16 && s < nk) pnext = psrc[s * (XP_STEP / 16) + tid]; };
-    auto store_p = [&](int s) { if (tid < XP_STEP / 16 && s < nk) *reinterpret_cast<uint4*>(lds + X_LDS_P + (s & (XP_RING - 1)) * XP_STEP + tid * 16) = pnext; };
+    auto load_p = [&](int s) { if (tid < PSTEP / 16 && s < nk) pnext = psrc[s * (PSTEP / 16) + tid]; };
+    auto store_p = [&](int s) { if (tid < PSTEP / 16 && s < nk) *reinterpret_cast<uint4*>(lds + X_LDS_P + (s & (XP_RING - 1)) * PSTEP + tid * 16) = pnext; };
     for (int s = 0; s < 3; ++s) { load_p(s); store_p(s); }
 
     // ---- producer geometry: lane -> 8-channel chunk of two pixels (rows r0, r0 + 64 of the tile)
@@ -372,8 +377,29 @@ __global__ void __launch_bounds__(512) k_dwpw_x(DwPwArgs p) {
             *reinterpret_cast<v4i*>(lds + X_LDS_AL + sw) = v4i{0, 0, 0, 0};
             return;
         }
-        const uint32_t* pp = reinterpret_cast<const uint32_t*>(lds + X_LDS_P + (s & (XP_RING - 1)) * XP_STEP + chunk * (11 * 8 * 4));
         float o[8];
+        if constexpr (F32W) {
+            const float* pf = reinterpret_cast<const float*>(lds + X_LDS_P + (s & (XP_RING - 1)) * PSTEP + chunk * (10 * 8 * 4));
+            {
+                const float4 b0 = DW_PARAM(float4, pf + 9 * 8), b1 = DW_PARAM(float4, pf + 9 * 8 + 4);
+                o[0] = b0.x; o[1] = b0.y; o[2] = b0.z; o[3] = b0.w;
+                o[4] = b1.x; o[5] = b1.y; o[6] = b1.z; o[7] = b1.w;
+            }
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float4 w0 = DW_PARAM(float4, pf + t * 8), w1 = DW_PARAM(float4, pf + t * 8 + 4);
+                const float wt[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int u = raw[q][t][j];        // (a copy first: __builtin_bit_cast of the vector-element expression itself read element 0 for every j)
+                    const h2 v = __builtin_bit_cast(h2, u);
+                    o[2 * j] = __builtin_fmaf((float)v[0], wt[2 * j], o[2 * j]);
+                    o[2 * j + 1] = __builtin_fmaf((float)v[1], wt[2 * j + 1], o[2 * j + 1]);
+                }
+            }
+        } else {
+        const uint32_t* pp = reinterpret_cast<const uint32_t*>(lds + X_LDS_P + (s & (XP_RING - 1)) * XP_STEP + chunk * (11 * 8 * 4));
         {
             const float4 b0 = DW_PARAM(float4, pp + 10 * 8), b1 = DW_PARAM(float4, pp + 10 * 8 + 4);
             o[0] = b0.x; o[1] = b0.y; o[2] = b0.z; o[3] = b0.w;
@@ -395,6 +421,7 @@ __global__ void __launch_bounds__(512) k_dwpw_x(DwPwArgs p) {
                 o[2 * j] = Half16<HT>::dot2(lo, wh[2 * j], Half16<HT>::dot2(lo, wlo[2 * j], o[2 * j]));
                 o[2 * j + 1] = Half16<HT>::dot2(hi, wh[2 * j + 1], Half16<HT>::dot2(hi, wlo[2 * j + 1], o[2 * j + 1]));
             }
+        }
         }
         float ol[8];
 #pragma unroll
@@ -501,11 +528,12 @@ __global__ void __launch_bounds__(512) k_dwpw_x(DwPwArgs p) {
     }
 }
 
+template <bool F32W>
 int launch_dwpw_x(const DwPwArgs& a, hipStream_t s) {
     constexpr int lds_bytes = X_LDS_P + XP_RING * XP_STEP;
     static_assert(lds_bytes <= 160 * 1024, "k_dwpw_x LDS");
-    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw_x), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(k_dwpw_x, dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
+    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw_x<F32W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_dwpw_x<F32W>, dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
@@ -522,8 +550,12 @@ int launch_dwpw_x(const DwPwArgs& a, hipStream_t s) {
 //   weight sub-slices and depthwise parameters come by LDS-DMA (no staging registers: 214 VGPRs).
 //   LDS: weight ring 2 x 32 KB | hi tiles 2 x 16 KB | lo tiles 2 x 16 KB | parameter ring 4 x 2.75 KB = 139 KB.
 constexpr int S_LDS_W = 0, S_LDS_AH = 2 * W_STAGE, S_LDS_AL = S_LDS_AH + 2 * A_STAGE, S_LDS_P = S_LDS_AL + 2 * A_STAGE;
-
+// F32W (w_split = 3): the depthwise weights are fp32, [K/64][chunk 8][row 10][8]: rows 0 .. 8 = the taps, row 9 = the bias; the depthwise stage is
+// then one v_fma_mix_f32 per tap, channel and input plane (f16 operand by op_sel, fp32 weight and sum) -- no tap-pair permutes, no hi / lo
+// weight parts: 144 vector instructions per pixel chunk instead of 200, at a cheaper issue rate (tools/micro/overlap.hip), and exact weights.
+template <bool F32W>
 __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
+    constexpr int PSTEP = F32W ? FP_STEP : XP_STEP;          // bytes of depthwise parameters per K-step
     typedef f16 HT;
     typedef typename Half16<HT>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -539,8 +571,8 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
     const unsigned lds0 = lds_addr(lds);
     // ---- depthwise parameters: K-step s -> ring slot s & 3; 2816 bytes = 176 lanes x 16 bytes, by LDS-DMA (waves 0 .. 2)
     auto dma_p = [&](int s) {
-        if (tid < XP_STEP / 16 && s < nk)
-            glds16_saddr(reinterpret_cast<const char*>(p.dwp) + s * XP_STEP, (unsigned)tid * 16u, lds0 + S_LDS_P + (s & (XP_RING - 1)) * XP_STEP + wave * 1024);
+        if (tid < PSTEP / 16 && s < nk)
+            glds16_saddr(reinterpret_cast<const char*>(p.dwp) + s * PSTEP, (unsigned)tid * 16u, lds0 + S_LDS_P + (s & (XP_RING - 1)) * PSTEP + wave * 1024);
     };
     for (int s = 0; s < 3; ++s) dma_p(s);
     // ---- producer geometry: lane -> 8-channel chunk of two pixels (rows r0, r0 + 64 of the tile).  A tap's byte offset is the pixel's
@@ -637,8 +669,43 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
             *reinterpret_cast<v4i*>(lds + S_LDS_AL + sw) = v4i{0, 0, 0, 0};
             return;
         }
-        const uint32_t* pp = reinterpret_cast<const uint32_t*>(lds + S_LDS_P + (s & (XP_RING - 1)) * XP_STEP + chunk * (11 * 8 * 4));
         float o[8];
+        if constexpr (F32W) {
+            const float* pf = reinterpret_cast<const float*>(lds + S_LDS_P + (s & (XP_RING - 1)) * PSTEP + chunk * (10 * 8 * 4));
+            {
+                const float4 b0 = DW_PARAM(float4, pf + 9 * 8), b1 = DW_PARAM(float4, pf + 9 * 8 + 4);
+                o[0] = b0.x; o[1] = b0.y; o[2] = b0.z; o[3] = b0.w;
+                o[4] = b1.x; o[5] = b1.y; o[6] = b1.z; o[7] = b1.w;
+            }
+            float wt[9][8];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float4 w0 = DW_PARAM(float4, pf + t * 8), w1 = DW_PARAM(float4, pf + t * 8 + 4);
+                wt[t][0] = w0.x; wt[t][1] = w0.y; wt[t][2] = w0.z; wt[t][3] = w0.w;
+                wt[t][4] = w1.x; wt[t][5] = w1.y; wt[t][6] = w1.z; wt[t][7] = w1.w;
+            }
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            // (the lo plane's products first: they are 2^-11 of the others)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int u = rl[t][j];            // (a copy first: __builtin_bit_cast of the vector-element expression itself read element 0 for every j)
+                    const h2 v = __builtin_bit_cast(h2, u);
+                    o[2 * j] = __builtin_fmaf((float)v[0], wt[t][2 * j], o[2 * j]);
+                    o[2 * j + 1] = __builtin_fmaf((float)v[1], wt[t][2 * j + 1], o[2 * j + 1]);
+                }
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int u = rh[t][j];
+                    const h2 v = __builtin_bit_cast(h2, u);
+                    o[2 * j] = __builtin_fmaf((float)v[0], wt[t][2 * j], o[2 * j]);
+                    o[2 * j + 1] = __builtin_fmaf((float)v[1], wt[t][2 * j + 1], o[2 * j + 1]);
+                }
+        } else {
+        const uint32_t* pp = reinterpret_cast<const uint32_t*>(lds + S_LDS_P + (s & (XP_RING - 1)) * XP_STEP + chunk * (11 * 8 * 4));
         {
             const float4 b0 = DW_PARAM(float4, pp + 10 * 8), b1 = DW_PARAM(float4, pp + 10 * 8 + 4);
             o[0] = b0.x; o[1] = b0.y; o[2] = b0.z; o[3] = b0.w;
@@ -663,6 +730,7 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
                 o[2 * j] = Half16<HT>::dot2(xe, wh[2 * j], Half16<HT>::dot2(xe, wlo[2 * j], Half16<HT>::dot2(le, wh[2 * j], o[2 * j])));
                 o[2 * j + 1] = Half16<HT>::dot2(xo, wh[2 * j + 1], Half16<HT>::dot2(xo, wlo[2 * j + 1], Half16<HT>::dot2(lo_, wh[2 * j + 1], o[2 * j + 1])));
             }
+        }
         }
         float ol[8];
 #pragma unroll
@@ -789,11 +857,12 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
     }
 }
 
+template <bool F32W>
 int launch_dwpw_xs(const DwPwArgs& a, hipStream_t s) {
     constexpr int lds_bytes = S_LDS_P + XP_RING * XP_STEP;
     static_assert(lds_bytes <= 160 * 1024, "k_dwpw_xs LDS");
-    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw_xs), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(k_dwpw_xs, dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
+    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw_xs<F32W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_dwpw_xs<F32W>, dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
@@ -814,8 +883,8 @@ int validate_dwpw(const avl_seg_op& op) {
     AVL_REQUIRE(op.in && op.out && op.weight && op.bias && op.in2, "dwpw has NULL buffers");
     AVL_REQUIRE(!op.w_split || op.dtype == AVL_F16, "split weights need AVL_F16 activations");
     AVL_REQUIRE(!op.in2_lo && (!op.out_lo || op.w_split), "dwpw: the output may be split only with w_split");
-    AVL_REQUIRE(!op.in_lo || op.w_split == 2, "dwpw: a split input (in_lo) needs the exact depthwise stage (w_split 2: k_dwpw_xs)");
-    AVL_REQUIRE(op.w_layout == 0 || (op.w_layout == 1 && op.in_lo && op.w_split == 2), "dwpw: w_layout 1 (8 x 16-pixel tiles) exists for the split-input kernel only");
+    AVL_REQUIRE(!op.in_lo || op.w_split >= 2, "dwpw: a split input (in_lo) needs the exact depthwise stage (w_split 2 or 3: k_dwpw_xs)");
+    AVL_REQUIRE(op.w_layout == 0 || (op.w_layout == 1 && op.in_lo && op.w_split >= 2), "dwpw: w_layout 1 (8 x 16-pixel tiles) exists for the split-input kernel only");
     AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.out_lo) | reinterpret_cast<uintptr_t>(op.in_lo)) % 16 == 0, "dwpw low planes must be 16-byte aligned");
     const int M = op.out_h * op.out_w, K = op.in_c, N = op.out_c;
     AVL_REQUIRE(op.stride == 1 && op.ksize == 3 && op.dil >= 1 && op.pad >= 0 && op.out_h == op.in_h + 2 * op.pad - 2 * op.dil &&
@@ -843,10 +912,12 @@ int launch_dwpw(const avl_seg_op& op, hipStream_t s) {
     const int mtiles = a.tiles_x > 0 ? a.tiles_x * ((op.out_h + 7) / 8) : (a.M + TM - 1) / TM;     // (the host's visiting order in2 has this many entries)
     a.mtiles = mtiles;
     a.per_xcd = (mtiles + 7) / 8;
-    a.order = reinterpret_cast<const int*>(a.dwp + (a.K / 64) * ((op.w_split == 2 ? XP_STEP : P_STEP) / 4));
+    a.order = reinterpret_cast<const int*>(a.dwp + (a.K / 64) * ((op.w_split == 3 ? FP_STEP : op.w_split == 2 ? XP_STEP : P_STEP) / 4));
     a.C_lo = op.out_lo;
-    if (op.w_split == 2 && op.in_lo) return launch_dwpw_xs(a, s);        // the same with a split input (the "mixed" decoder, the split16 ASPP)
-    if (op.w_split == 2) return launch_dwpw_x(a, s);         // exact depthwise stage: f16 weight pairs, split tile (pack_dw_pairs(split=True))
+    // exact depthwise stage (split tile, three MFMA passes): w_split 3 = fp32 depthwise weights (pack_dw_f32), 2 = f16 weight pairs (pack_dw_pairs_split);
+    // with in_lo the input is two planes (the "mixed" decoder, the split16 ASPP)
+    if (op.w_split == 3) return op.in_lo ? launch_dwpw_xs<true>(a, s) : launch_dwpw_x<true>(a, s);
+    if (op.w_split == 2) return op.in_lo ? launch_dwpw_xs<false>(a, s) : launch_dwpw_x<false>(a, s);
     if (op.w_split) return launch_dwpw_typed<f16, 2>(a, mtiles, s);
     return op.dtype == AVL_F16 ? launch_dwpw_typed<f16, 1>(a, mtiles, s) : launch_dwpw_typed<bf16, 1>(a, mtiles, s);
 }

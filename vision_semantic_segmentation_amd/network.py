@@ -272,6 +272,18 @@ def pack_dw_pairs_split(w, b):
     return out.reshape(-1)
 
 
+def pack_dw_f32(w, b):
+    """Depthwise parameters for k_dwpw_xs<F32W> (w_split = 3 of AVL_OP_DWPW: split input, fp32 depthwise weights): w float64 [C][1][3][3]
+    and b [C] (BN folded) -> the int32 bit patterns of float32 [C/64][chunk 8][row 10][8]: rows 0 .. 8 = tap t of the chunk's eight
+    channels, row 9 = the bias."""
+    c = w.shape[0]
+    assert c % 64 == 0
+    out = torch.empty((c // 64, 8, 10, 8), dtype=torch.float32)
+    out[:, :, 0:9, :] = w.reshape(c // 64, 8, 8, 9).permute(0, 1, 3, 2).to(torch.float32)
+    out[:, :, 9, :] = b.to(torch.float32).reshape(c // 64, 8, 8)
+    return out.view(torch.int32).reshape(-1)
+
+
 def pack_dw_pairs(w, b, act_dtype):
     """Depthwise parameters for the fused depthwise+pointwise kernel (AVL_OP_DWPW): w float64 [C][1][3][3] and b [C]
     (BN folded) -> int32 [C/64][chunk 8][6][8]: five tap pairs per channel (tap 2p in the low half, tap 2p+1 in the
@@ -746,10 +758,10 @@ class SegNet(object):
         wdev = self._dev(pack_split_rows(wp, 2), torch.float16) if self.mixed else self._dev(wp, self.act_dtype)
         bdev = self._dev(bp, torch.float32)
         exact = self.mixed and self.mixed_dw_exact
-        dwp = pack_dw_pairs_split(w_dw, b_dw) if exact else pack_dw_pairs(w_dw, b_dw, self.act_dtype)
-        # a split input (hi + lo planes) goes through k_dwpw_xs, which exists with the exact depthwise stage only; its stride-1 form
-        # (the decoder) walks 8 x 16-pixel blocks
+        # exact: fp32 depthwise weights (w_split 3), the depthwise result as a split tile; a split input (hi + lo planes) exists in this form
+        # only (k_dwpw_xs), its stride-1 case (the decoder) walks 8 x 16-pixel blocks
         in_lo = self._lo(src) if exact else 0
+        dwp = pack_dw_f32(w_dw, b_dw) if exact else pack_dw_pairs(w_dw, b_dw, self.act_dtype)
         blocks = bool(in_lo) and dilation == 1
         params = torch.cat([dwp, dwpw_block_order(oh, ow) if blocks else dwpw_tile_order(oh, ow, dilation)]).to(self.device)
         self._keep.append(params)
@@ -757,7 +769,7 @@ class SegNet(object):
         op_, old, orows = self._view(dst, dst_col)
         self._op(name, OP_DWPW, in_=ip, in_lo=in_lo, in2=params.data_ptr(), out=op_, weight=wdev.data_ptr(), bias=bdev.data_ptr(), in_h=h, in_w=wd,
                  in_c=cin, in_ld=ild, in_rows=irows, out_h=oh, out_w=ow, out_c=cout, out_ld=old, out_rows=orows, relu=1, w_rows=w_rows,
-                 ksize=3, stride=1, pad=padding, dil=dilation, groups=cin, w_split=(2 if exact else int(self.mixed)), w_layout=int(blocks),
+                 ksize=3, stride=1, pad=padding, dil=dilation, groups=cin, w_split=(3 if exact else int(self.mixed)), w_layout=int(blocks),
                  out_lo=self._lo(dst, dst_col) if self.mixed else 0)
 
     def _spatial(self, name, kind, src, in_hw, cin, dst, out_hw, cout, weight=None, bias=None, dst_col=0, **extra):
