@@ -242,14 +242,12 @@ int avl_eval_map(const uint8_t* color_map, int H, int W, const uint8_t* mask, in
                                 [K/64][8][6][8] dwords: five tap pairs (taps 2p | 2p+1 << 16 in the activation type)
                                 and the fp32 bias of each 8-channel chunk; then int32[ceil(H*W/128)]: the order in
                                 which the 128-pixel tiles are visited (a permutation; tiles a dilation apart adjacent).
-                                w_split = 2 (AVL_F16): the EXACT depthwise stage -- depthwise weights as f16 pairs hi + lo
-                                and a split depthwise result; in2 = [K/64][8][11][8] dwords per 8-channel chunk: five
-                                tap pairs of the hi parts, five of the lo parts, the fp32 bias; then the tile order as
-                                above.  `weight` is the 1x1 conv's [n][K/64][hi 64 | lo 64] as for w_split = 1.
-                                w_split = 3 (AVL_F16; what the "mixed" network emits): the same exact stage with FP32 depthwise
-                                weights -- in2 = float32 [K/64][8][10][8] per 8-channel chunk: rows 0 .. 8 = tap t of the chunk's
-                                eight channels, row 9 = the bias; then the tile order.
-                                With in_lo (w_split = 2 or 3): the input is two f16 planes (the "mixed" decoder's refine blocks,
+                                w_split = 3 (AVL_F16; what the "mixed" network emits): the EXACT depthwise stage -- FP32 depthwise
+                                weights and a split depthwise result (three MFMA passes); in2 = float32 [K/64][8][10][8] per
+                                8-channel chunk: rows 0 .. 8 = tap t of the chunk's eight channels, row 9 = the bias; then the
+                                tile order as above.  `weight` is the 1x1 conv's [n][K/64][hi 64 | lo 64] as for w_split = 1.
+                                (w_split = 2 -- depthwise weights as f16 pairs, rounds 3-5 -- is no longer accepted.)
+                                With in_lo (w_split = 3): the input is two f16 planes (the "mixed" decoder's refine blocks,
                                 decoder.py:33-43; the ASPP branches of the complete hi + lo plan).  w_layout = 1 (with in_lo):
                                 a tile is an 8 x 16 block of output pixels instead of 128 consecutive ones; the order array
                                 then has ceil(out_h / 8) * ceil(out_w / 16) entries (tile = block row * ceil(out_w / 16) + block column). */

@@ -181,17 +181,16 @@ def test_split_fused_depthwise_pointwise(case, cuda_device):
     assert torch.all(out[:, M:] == 7.0)
 
 
-@pytest.mark.parametrize("wsplit", [3, 2])
 @pytest.mark.parametrize("case", [(37, 53, 128, 256, 12), (20, 31, 2048, 256, 24), (16, 16, 256, 512, 1), (45, 80, 2048, 256, 36)])
-def test_exact_fused_depthwise_pointwise(case, wsplit, cuda_device):
-    """AVL_OP_DWPW with w_split = 2 (k_dwpw_x, the ASPP branches of the default mixed mode): depthwise weights as f16 pairs, the
+def test_exact_fused_depthwise_pointwise(case, cuda_device):
+    """AVL_OP_DWPW with w_split = 3 (k_dwpw_x, the ASPP branches of the default mixed mode): fp32 depthwise weights, the
     depthwise result as an f16 hi + lo tile, three MFMA passes -- against a float64 evaluation of the SAME operands (the f16
-    input plane; the weights hi + lo): nothing but fp32 accumulation is rounded away."""
+    input plane; the fp32 depthwise weights; the 1x1 weights hi + lo): nothing but fp32 accumulation is rounded away."""
     import torch
     import torch.nn.functional as F
     from test_gpu_ops import _from_rows, _nhwc_rows
     from vision_semantic_segmentation_amd import _lib
-    from vision_semantic_segmentation_amd.network import OP_DWPW, AvlSegOp, dwpw_tile_order, pack_dw_f32, pack_dw_pairs_split, pack_split_rows, split_f16
+    from vision_semantic_segmentation_amd.network import OP_DWPW, AvlSegOp, dwpw_tile_order, pack_dw_f32, pack_split_rows, split_f16
     H, W, K, N, d = case
     g = torch.Generator().manual_seed(H * 31 + W + K + d + 1)
     x = torch.randn((1, K, H, W), generator=g).to(torch.float16)
@@ -208,18 +207,16 @@ def test_exact_fused_depthwise_pointwise(case, wsplit, cuda_device):
     b2p[:N] = b2
     w2d, b2d = pack_split_rows(w2p, 2).to(cuda_device), b2p.to(cuda_device)
     out = torch.full((2, Mp, N), 7.0, dtype=torch.float16, device=cuda_device)
-    params = torch.cat([pack_dw_f32(w1, b1) if wsplit == 3 else pack_dw_pairs_split(w1, b1), dwpw_tile_order(H, W, d)]).to(cuda_device)
+    params = torch.cat([pack_dw_f32(w1, b1), dwpw_tile_order(H, W, d)]).to(cuda_device)
     op = AvlSegOp()
     op.kind, op.dtype = OP_DWPW, _lib.AVL_F16
     op.in_, op.in2, op.out, op.out_lo = src.data_ptr(), params.data_ptr(), out[0].data_ptr(), out[1].data_ptr()
-    op.weight, op.bias, op.w_split = w2d.data_ptr(), b2d.data_ptr(), wsplit
+    op.weight, op.bias, op.w_split = w2d.data_ptr(), b2d.data_ptr(), 3
     op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = H, W, K, K, src.shape[0]
     op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = H, W, N, N, Mp
     op.relu, op.w_rows, op.ksize, op.stride, op.pad, op.dil, op.groups = 1, Np, 3, 1, d, d, K
     _run_plan([op])
-    w1h, w1l = split_f16(w1.reshape(K, 9))
-    # what the kernel multiplies with: the fp32 weights (w_split 3, what the network emits), or f16 pairs hi + lo (w_split 2)
-    w1s = w1.float().double() if wsplit == 3 else (w1h.double() + w1l.double()).reshape(K, 1, 3, 3)
+    w1s = w1.float().double()                                                # what the kernel multiplies with: the fp32 weights
     b1s = b1.to(torch.float32).double()
     a64 = F.relu(F.conv2d(x.double(), w1s, b1s, padding=d, dilation=d, groups=K))
     ah, al = _split(a64)                                                      # the tile the kernel keeps: f16 hi + f16 lo
@@ -233,22 +230,21 @@ def test_exact_fused_depthwise_pointwise(case, wsplit, cuda_device):
     assert torch.all(out[:, M:] == 7.0)
 
 
-@pytest.mark.parametrize("wsplit", [3, 2])
 @pytest.mark.parametrize("case", [(37, 53, 512, 256, 1, 0, 0), (37, 53, 512, 256, 1, 0, 1), (20, 31, 256, 256, 1, 0, 1), (30, 40, 1024, 256, 12, 12, 0), (16, 16, 64, 512, 1, 1, 0),
                                   (16, 16, 64, 512, 1, 1, 1), (9, 140, 128, 64, 2, 0, 0), (11, 70, 128, 64, 1, 0, 1)])
-def test_exact_fused_depthwise_pointwise_with_a_split_input(case, wsplit, cuda_device):
-    """round 5: AVL_OP_DWPW with w_split = 2 AND in_lo (k_dwpw_xs: the mixed decoder's refine blocks decoder.py:33-43 -- pad 0 --, the
-    split16 plan's ASPP branches): input hi + lo planes, (xh + xl)(wh + wl) without the lo x lo term (2^-22), everything else as
-    k_dwpw_x -- against a float64 evaluation of the same operands.  wsplit 3 (what the network emits): fp32 depthwise weights, one
-    v_fma_mix_f32 per tap, channel and plane; wsplit 2: f16 weight pairs and v_dot2c, as k_dwpw_x.  Cases (last number: w_layout, 1 = 8 x 16-pixel tiles as the decoder
+def test_exact_fused_depthwise_pointwise_with_a_split_input(case, cuda_device):
+    """round 5: AVL_OP_DWPW with w_split = 3 AND in_lo (k_dwpw_xs: the mixed decoder's refine blocks decoder.py:33-43 -- pad 0 --, the
+    split16 plan's ASPP branches): input hi + lo planes, everything else as
+    k_dwpw_x (fp32 depthwise weights, one v_fma_mix_f32 per tap, channel and plane) -- against a float64 evaluation of the same operands.
+    Cases (last number: w_layout, 1 = 8 x 16-pixel tiles as the decoder
     uses them, block counts that do not divide the output): the decoder's two shapes, a dilated padded branch, two output-channel
     tiles, a tile spanning several image rows with K = 2 steps."""
     import torch
     import torch.nn.functional as F
     from test_gpu_ops import _from_rows, _nhwc_rows
     from vision_semantic_segmentation_amd import _lib
-    from vision_semantic_segmentation_amd.network import (OP_DWPW, AvlSegOp, dwpw_block_order, dwpw_tile_order, pack_dw_f32, pack_dw_pairs_split,
-                                                          pack_split_rows, split_f16)
+    from vision_semantic_segmentation_amd.network import (OP_DWPW, AvlSegOp, dwpw_block_order, dwpw_tile_order, pack_dw_f32, pack_split_rows,
+                                                          split_f16)
     H, W, K, N, d, pad, blocks = case
     OH, OW = H + 2 * pad - 2 * d, W + 2 * pad - 2 * d
     g = torch.Generator().manual_seed(H * 31 + W + K + d + 7)
@@ -267,18 +263,16 @@ def test_exact_fused_depthwise_pointwise_with_a_split_input(case, wsplit, cuda_d
     b2p[:N] = b2
     w2d, b2d = pack_split_rows(w2p, 2).to(cuda_device), b2p.to(cuda_device)
     out = torch.full((2, Mp, N), 7.0, dtype=torch.float16, device=cuda_device)
-    params = torch.cat([pack_dw_f32(w1, b1) if wsplit == 3 else pack_dw_pairs_split(w1, b1),
-                        dwpw_block_order(OH, OW) if blocks else dwpw_tile_order(OH, OW, d)]).to(cuda_device)
+    params = torch.cat([pack_dw_f32(w1, b1), dwpw_block_order(OH, OW) if blocks else dwpw_tile_order(OH, OW, d)]).to(cuda_device)
     op = AvlSegOp()
     op.kind, op.dtype = OP_DWPW, _lib.AVL_F16
     op.in_, op.in_lo, op.in2, op.out, op.out_lo = src[0].data_ptr(), src[1].data_ptr(), params.data_ptr(), out[0].data_ptr(), out[1].data_ptr()
-    op.weight, op.bias, op.w_split, op.w_layout = w2d.data_ptr(), b2d.data_ptr(), wsplit, blocks
+    op.weight, op.bias, op.w_split, op.w_layout = w2d.data_ptr(), b2d.data_ptr(), 3, blocks
     op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = H, W, K, K, src.shape[1]
     op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = OH, OW, N, N, Mp
     op.relu, op.w_rows, op.ksize, op.stride, op.pad, op.dil, op.groups = 1, Np, 3, 1, pad, d, K
     _run_plan([op])
-    w1h, w1l = split_f16(w1.reshape(K, 9))
-    w1s = (w1h.double() + w1l.double()).reshape(K, 1, 3, 3) if wsplit == 2 else w1.float().double()      # what the kernel multiplies with
+    w1s = w1.float().double()                                                # what the kernel multiplies with
     b1s = b1.to(torch.float32).double()
     a64 = F.relu(F.conv2d(xh.double() + xl.double(), w1s, b1s, padding=pad, dilation=d, groups=K))
     ah, al = _split(a64)

@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 from vision_semantic_segmentation_amd import _lib  # noqa: E402
-from vision_semantic_segmentation_amd.network import OP_DWPW, AvlSegOp, dwpw_block_order, dwpw_tile_order, pack_dw_f32, pack_dw_pairs_split, pack_split_rows  # noqa: E402
+from vision_semantic_segmentation_amd.network import OP_DWPW, AvlSegOp, dwpw_block_order, dwpw_tile_order, pack_dw_f32, pack_split_rows  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 dev = torch.device("cuda:0")
@@ -31,8 +31,7 @@ for (name, H, W, K, N, d, pad, split_in) in CASES:
     b2 = torch.randn(Np, generator=g)
     xd, w2d, b2d = x.to(dev), pack_split_rows(w2, 2).to(dev), b2.to(dev)
     blocks = split_in and d == 1 and not os.environ.get("DWPW_ROW_TILES")       # 8 x 16-pixel tiles, as the network's decoder uses them
-    f32w = not os.environ.get("DWPW_F16_PAIRS")                    # fp32 depthwise weights (w_split 3), as the network uses them
-    params = torch.cat([pack_dw_f32(w1, b1) if f32w else pack_dw_pairs_split(w1, b1), dwpw_block_order(OH, OW) if blocks else dwpw_tile_order(OH, OW, d)]).to(dev)
+    params = torch.cat([pack_dw_f32(w1, b1), dwpw_block_order(OH, OW) if blocks else dwpw_tile_order(OH, OW, d)]).to(dev)
     out = torch.zeros((2, Mp, N), dtype=torch.float16, device=dev)
     op = AvlSegOp()
     op.kind, op.dtype = OP_DWPW, _lib.AVL_F16
@@ -41,7 +40,7 @@ for (name, H, W, K, N, d, pad, split_in) in CASES:
         op.in_lo = xd[1].data_ptr()
     op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = H, W, K, K, Mip
     op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = OH, OW, N, N, Mp
-    op.relu, op.w_rows, op.ksize, op.stride, op.pad, op.dil, op.groups, op.w_split, op.w_layout = 1, Np, 3, 1, pad, d, K, 3 if f32w else 2, int(blocks)
+    op.relu, op.w_rows, op.ksize, op.stride, op.pad, op.dil, op.groups, op.w_split, op.w_layout = 1, Np, 3, 1, pad, d, K, 3, int(blocks)
     plan = C.c_void_p()
     _lib.check(_lib.lib().avl_seg_plan_create((AvlSegOp * 1)(op), 1, C.byref(plan)))
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -263,22 +263,21 @@ __global__ void __launch_bounds__(512) k_dwpw(DwPwArgs p) {
 // Measured on the worst weights draw at 1080p (tools/opt_sweep.py): the two roundings the fused kernel above adds to the split
 // pipeline -- depthwise weights as ONE f16 each, the depthwise result as ONE f16 plane in LDS -- carried 47 % of the logits' error
 // energy (rms 1.59e-4 -> 1.16e-4 with the branches run unfused through the split depthwise kernel; weights 2/3 of it, result 1/3).
-// Here: depthwise weights as f16 PAIRS hi + lo (two v_dot2c per tap pair), the result split into an f16 hi tile and an f16 lo tile
-// in LDS, and three MFMA passes per 64-wide K-step: Wh.th + Wh.tl (sub-step j = 0, weight slice hi) and Wl.th (j = 1, slice lo).
+// Here: FP32 depthwise weights (w_split = 3; float32 [K/64][chunk 8][row 10][8]: rows 0 .. 8 = the taps, row 9 = the bias), one v_fma_mix_f32
+// per tap and channel (f16 operand by op_sel, fp32 weight and sum); the result split into an f16 hi tile and an f16 lo tile in LDS, and three
+// MFMA passes per 64-wide K-step: Wh.th + Wh.tl (sub-step j = 0, weight slice hi) and Wl.th (j = 1, slice lo).
+// (Round 3's depthwise stage -- weights as f16 pairs hi + lo, tap-pair permutes + two v_dot2c -- took 120 vector instructions per pixel chunk
+//  instead of 72 and 6 % longer per launch: profiles/r05/dwpw_phase_ablation.log.)
 //   LDS: weight ring 2 x 32 KB | hi tiles 2 x 16 KB | lo tile 16 KB (written in sub-step j = 1 of step s - 1, read in j = 0 of
-//   step s) | a ring of four K-steps' depthwise parameters (11 rows x 8 dwords per 8-channel chunk: 5 tap pairs hi, 5 lo, bias),
-//   refilled three steps ahead by the first 176 lanes: with hi + lo the parameters of all K-steps (88 KB) no longer fit.
+//   step s) | a ring of four K-steps' depthwise parameters, refilled three steps ahead by the first 160 lanes (the parameters of all 32 K-steps
+//   of an ASPP branch, 80 KB, do not fit).
 //   The whole depthwise slice s + 1 is computed during sub-step j = 1 (32 MFMAs), j = 0 carries 64 MFMAs.
 constexpr int X_LDS_W = 0, X_LDS_AH = 2 * W_STAGE, X_LDS_AL = X_LDS_AH + 2 * A_STAGE, X_LDS_P = X_LDS_AL + A_STAGE;
-constexpr int XP_STEP = 8 * 11 * 8 * 4;             // 2816 bytes of depthwise parameters per K-step
 constexpr int XP_RING = 4;
-constexpr int FP_STEP = 8 * 10 * 8 * 4;              // F32W (w_split = 3): fp32 depthwise weights, [K/64][chunk 8][row 10][8]: rows 0 .. 8 = the taps, row 9 = the bias: 2560 bytes
+constexpr int FP_STEP = 8 * 10 * 8 * 4;              // 2560 bytes of depthwise parameters per K-step
 
-// F32W: one v_fma_mix_f32 per tap and channel (f16 operand by op_sel, fp32 weight and sum) instead of tap-pair permutes + two v_dot2c (hi / lo weight parts):
-// 72 vector instructions per pixel chunk instead of 120, at a cheaper issue rate (tools/micro/overlap.hip), exact weights.
-template <bool F32W>
 __global__ void __launch_bounds__(512) k_dwpw_x(DwPwArgs p) {
-    constexpr int PSTEP = F32W ? FP_STEP : XP_STEP;          // bytes of depthwise parameters per K-step
+    constexpr int PSTEP = FP_STEP;          // bytes of depthwise parameters per K-step
     typedef f16 HT;
     typedef typename Half16<HT>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -378,50 +377,24 @@ __global__ void __launch_bounds__(512) k_dwpw_x(DwPwArgs p) {
             return;
         }
         float o[8];
-        if constexpr (F32W) {
-            const float* pf = reinterpret_cast<const float*>(lds + X_LDS_P + (s & (XP_RING - 1)) * PSTEP + chunk * (10 * 8 * 4));
-            {
-                const float4 b0 = DW_PARAM(float4, pf + 9 * 8), b1 = DW_PARAM(float4, pf + 9 * 8 + 4);
-                o[0] = b0.x; o[1] = b0.y; o[2] = b0.z; o[3] = b0.w;
-                o[4] = b1.x; o[5] = b1.y; o[6] = b1.z; o[7] = b1.w;
-            }
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float4 w0 = DW_PARAM(float4, pf + t * 8), w1 = DW_PARAM(float4, pf + t * 8 + 4);
-                const float wt[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int u = raw[q][t][j];        // (a copy first: __builtin_bit_cast of the vector-element expression itself read element 0 for every j)
-                    const h2 v = __builtin_bit_cast(h2, u);
-                    o[2 * j] = __builtin_fmaf((float)v[0], wt[2 * j], o[2 * j]);
-                    o[2 * j + 1] = __builtin_fmaf((float)v[1], wt[2 * j + 1], o[2 * j + 1]);
-                }
-            }
-        } else {
-        const uint32_t* pp = reinterpret_cast<const uint32_t*>(lds + X_LDS_P + (s & (XP_RING - 1)) * XP_STEP + chunk * (11 * 8 * 4));
+        const float* pf = reinterpret_cast<const float*>(lds + X_LDS_P + (s & (XP_RING - 1)) * PSTEP + chunk * (10 * 8 * 4));
         {
-            const float4 b0 = DW_PARAM(float4, pp + 10 * 8), b1 = DW_PARAM(float4, pp + 10 * 8 + 4);
+            const float4 b0 = DW_PARAM(float4, pf + 9 * 8), b1 = DW_PARAM(float4, pf + 9 * 8 + 4);
             o[0] = b0.x; o[1] = b0.y; o[2] = b0.z; o[3] = b0.w;
             o[4] = b1.x; o[5] = b1.y; o[6] = b1.z; o[7] = b1.w;
         }
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int pr = 0; pr < 5; ++pr) {
-            const uint4 h0 = DW_PARAM(uint4, pp + pr * 8), h1 = DW_PARAM(uint4, pp + pr * 8 + 4);
-            const uint4 l0 = DW_PARAM(uint4, pp + (5 + pr) * 8), l1 = DW_PARAM(uint4, pp + (5 + pr) * 8 + 4);
-            const uint32_t wh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-            const uint32_t wlo[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-            const v4i ra = raw[q][2 * pr], rb = raw[q][pr < 4 ? 2 * pr + 1 : 8];
+        for (int t = 0; t < 9; ++t) {
+            const float4 w0 = DW_PARAM(float4, pf + t * 8), w1 = DW_PARAM(float4, pf + t * 8 + 4);
+            const float wt[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t ua = (uint32_t)ra[j], ub = (uint32_t)rb[j];
-                const uint32_t lo = pr < 4 ? __builtin_amdgcn_perm(ub, ua, 0x05040100u) : (ua & 0xffffu);
-                const uint32_t hi = pr < 4 ? __builtin_amdgcn_perm(ub, ua, 0x07060302u) : (ua >> 16);
-                // (the lo products first: they are 2^-11 of the hi ones)
-                o[2 * j] = Half16<HT>::dot2(lo, wh[2 * j], Half16<HT>::dot2(lo, wlo[2 * j], o[2 * j]));
-                o[2 * j + 1] = Half16<HT>::dot2(hi, wh[2 * j + 1], Half16<HT>::dot2(hi, wlo[2 * j + 1], o[2 * j + 1]));
+                const int u = raw[q][t][j];        // (a copy first: __builtin_bit_cast of the vector-element expression itself read element 0 for every j)
+                const h2 v = __builtin_bit_cast(h2, u);
+                o[2 * j] = __builtin_fmaf((float)v[0], wt[2 * j], o[2 * j]);
+                o[2 * j + 1] = __builtin_fmaf((float)v[1], wt[2 * j + 1], o[2 * j + 1]);
             }
-        }
         }
         float ol[8];
 #pragma unroll
@@ -528,12 +501,11 @@ __global__ void __launch_bounds__(512) k_dwpw_x(DwPwArgs p) {
     }
 }
 
-template <bool F32W>
 int launch_dwpw_x(const DwPwArgs& a, hipStream_t s) {
-    constexpr int lds_bytes = X_LDS_P + XP_RING * XP_STEP;
+    constexpr int lds_bytes = X_LDS_P + XP_RING * FP_STEP;
     static_assert(lds_bytes <= 160 * 1024, "k_dwpw_x LDS");
-    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw_x<F32W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(k_dwpw_x<F32W>, dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
+    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw_x), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_dwpw_x, dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
@@ -543,19 +515,15 @@ int launch_dwpw_x(const DwPwArgs& a, hipStream_t s) {
 // (decoder.py:33-43: depthwise 3x3 pad 0 + BN + ReLU, 1x1 + BN + ReLU on concat(upsampled ASPP, low-level) and on its result) and the
 // ASPP branches of the split16 plan.  Unfused, the depthwise result went to HBM as two planes (+ FP4 copies) and came back into the
 // 1x1 GEMM: 2 x 265 MB + 2 x 131 MB per frame at 1080p for 2.7 GMAC.
-//   depthwise stage: (xh + xl) . (wh + wl) as xl.wh + xh.wl + xh.wh, three v_dot2c per tap pair and channel, fp32 sums (small terms first);
+//   depthwise stage: (xh + xl) . w with fp32 weights: one v_fma_mix_f32 per tap, channel and plane, the lo plane's products first;
 //   the tap registers hold ONE pixel's nine taps of both planes (72 VGPRs, as many as k_dwpw_x's two pixels of one plane): pixel 0 of
 //   slice s + 1 is produced during sub-step j = 0 of step s and pixel 1 during j = 1, each pixel's taps requested as soon as the other
 //   pixel's registers are free (48 MFMAs per wave ahead of their use); the lo tile has two slots like the hi tile for that;
-//   weight sub-slices and depthwise parameters come by LDS-DMA (no staging registers: 214 VGPRs).
-//   LDS: weight ring 2 x 32 KB | hi tiles 2 x 16 KB | lo tiles 2 x 16 KB | parameter ring 4 x 2.75 KB = 139 KB.
+//   weight sub-slices and depthwise parameters come by LDS-DMA (no staging registers: 246 VGPRs).
+//   LDS: weight ring 2 x 32 KB | hi tiles 2 x 16 KB | lo tiles 2 x 16 KB | parameter ring 4 x 2.5 KB = 138 KB.
 constexpr int S_LDS_W = 0, S_LDS_AH = 2 * W_STAGE, S_LDS_AL = S_LDS_AH + 2 * A_STAGE, S_LDS_P = S_LDS_AL + 2 * A_STAGE;
-// F32W (w_split = 3): the depthwise weights are fp32, [K/64][chunk 8][row 10][8]: rows 0 .. 8 = the taps, row 9 = the bias; the depthwise stage is
-// then one v_fma_mix_f32 per tap, channel and input plane (f16 operand by op_sel, fp32 weight and sum) -- no tap-pair permutes, no hi / lo
-// weight parts: 144 vector instructions per pixel chunk instead of 200, at a cheaper issue rate (tools/micro/overlap.hip), and exact weights.
-template <bool F32W>
 __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
-    constexpr int PSTEP = F32W ? FP_STEP : XP_STEP;          // bytes of depthwise parameters per K-step
+    constexpr int PSTEP = FP_STEP;          // bytes of depthwise parameters per K-step
     typedef f16 HT;
     typedef typename Half16<HT>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -670,68 +638,39 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
             return;
         }
         float o[8];
-        if constexpr (F32W) {
-            const float* pf = reinterpret_cast<const float*>(lds + S_LDS_P + (s & (XP_RING - 1)) * PSTEP + chunk * (10 * 8 * 4));
-            {
-                const float4 b0 = DW_PARAM(float4, pf + 9 * 8), b1 = DW_PARAM(float4, pf + 9 * 8 + 4);
-                o[0] = b0.x; o[1] = b0.y; o[2] = b0.z; o[3] = b0.w;
-                o[4] = b1.x; o[5] = b1.y; o[6] = b1.z; o[7] = b1.w;
-            }
-            float wt[9][8];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float4 w0 = DW_PARAM(float4, pf + t * 8), w1 = DW_PARAM(float4, pf + t * 8 + 4);
-                wt[t][0] = w0.x; wt[t][1] = w0.y; wt[t][2] = w0.z; wt[t][3] = w0.w;
-                wt[t][4] = w1.x; wt[t][5] = w1.y; wt[t][6] = w1.z; wt[t][7] = w1.w;
-            }
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            // (the lo plane's products first: they are 2^-11 of the others)
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int u = rl[t][j];            // (a copy first: __builtin_bit_cast of the vector-element expression itself read element 0 for every j)
-                    const h2 v = __builtin_bit_cast(h2, u);
-                    o[2 * j] = __builtin_fmaf((float)v[0], wt[t][2 * j], o[2 * j]);
-                    o[2 * j + 1] = __builtin_fmaf((float)v[1], wt[t][2 * j + 1], o[2 * j + 1]);
-                }
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int u = rh[t][j];
-                    const h2 v = __builtin_bit_cast(h2, u);
-                    o[2 * j] = __builtin_fmaf((float)v[0], wt[t][2 * j], o[2 * j]);
-                    o[2 * j + 1] = __builtin_fmaf((float)v[1], wt[t][2 * j + 1], o[2 * j + 1]);
-                }
-        } else {
-        const uint32_t* pp = reinterpret_cast<const uint32_t*>(lds + S_LDS_P + (s & (XP_RING - 1)) * XP_STEP + chunk * (11 * 8 * 4));
+        const float* pf = reinterpret_cast<const float*>(lds + S_LDS_P + (s & (XP_RING - 1)) * PSTEP + chunk * (10 * 8 * 4));
         {
-            const float4 b0 = DW_PARAM(float4, pp + 10 * 8), b1 = DW_PARAM(float4, pp + 10 * 8 + 4);
+            const float4 b0 = DW_PARAM(float4, pf + 9 * 8), b1 = DW_PARAM(float4, pf + 9 * 8 + 4);
             o[0] = b0.x; o[1] = b0.y; o[2] = b0.z; o[3] = b0.w;
             o[4] = b1.x; o[5] = b1.y; o[6] = b1.z; o[7] = b1.w;
         }
+        float wt[9][8];
 #pragma unroll
-        for (int pr = 0; pr < 5; ++pr) {
-            const uint4 h0 = DW_PARAM(uint4, pp + pr * 8), h1 = DW_PARAM(uint4, pp + pr * 8 + 4);
-            const uint4 l0 = DW_PARAM(uint4, pp + (5 + pr) * 8), l1 = DW_PARAM(uint4, pp + (5 + pr) * 8 + 4);
-            const uint32_t wh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-            const uint32_t wlo[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-            const v4i ra = rh[2 * pr], rb = rh[pr < 4 ? 2 * pr + 1 : 8];
-            const v4i la = rl[2 * pr], lb = rl[pr < 4 ? 2 * pr + 1 : 8];
+        for (int t = 0; t < 9; ++t) {
+            const float4 w0 = DW_PARAM(float4, pf + t * 8), w1 = DW_PARAM(float4, pf + t * 8 + 4);
+            wt[t][0] = w0.x; wt[t][1] = w0.y; wt[t][2] = w0.z; wt[t][3] = w0.w;
+            wt[t][4] = w1.x; wt[t][5] = w1.y; wt[t][6] = w1.z; wt[t][7] = w1.w;
+        }
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        // (the lo plane's products first: they are 2^-11 of the others)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t ua = (uint32_t)ra[j], ub = (uint32_t)rb[j], va = (uint32_t)la[j], vb = (uint32_t)lb[j];
-                const uint32_t xe = pr < 4 ? __builtin_amdgcn_perm(ub, ua, 0x05040100u) : (ua & 0xffffu);     // even channel: taps 2p | 2p+1
-                const uint32_t xo = pr < 4 ? __builtin_amdgcn_perm(ub, ua, 0x07060302u) : (ua >> 16);
-                const uint32_t le = pr < 4 ? __builtin_amdgcn_perm(vb, va, 0x05040100u) : (va & 0xffffu);
-                const uint32_t lo_ = pr < 4 ? __builtin_amdgcn_perm(vb, va, 0x07060302u) : (va >> 16);
-                // (the two small products first: each is 2^-11 of the hi x hi one)
-                o[2 * j] = Half16<HT>::dot2(xe, wh[2 * j], Half16<HT>::dot2(xe, wlo[2 * j], Half16<HT>::dot2(le, wh[2 * j], o[2 * j])));
-                o[2 * j + 1] = Half16<HT>::dot2(xo, wh[2 * j + 1], Half16<HT>::dot2(xo, wlo[2 * j + 1], Half16<HT>::dot2(lo_, wh[2 * j + 1], o[2 * j + 1])));
+                const int u = rl[t][j];            // (a copy first: __builtin_bit_cast of the vector-element expression itself read element 0 for every j)
+                const h2 v = __builtin_bit_cast(h2, u);
+                o[2 * j] = __builtin_fmaf((float)v[0], wt[t][2 * j], o[2 * j]);
+                o[2 * j + 1] = __builtin_fmaf((float)v[1], wt[t][2 * j + 1], o[2 * j + 1]);
             }
-        }
-        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int u = rh[t][j];
+                const h2 v = __builtin_bit_cast(h2, u);
+                o[2 * j] = __builtin_fmaf((float)v[0], wt[t][2 * j], o[2 * j]);
+                o[2 * j + 1] = __builtin_fmaf((float)v[1], wt[t][2 * j + 1], o[2 * j + 1]);
+            }
         float ol[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -857,12 +796,11 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
     }
 }
 
-template <bool F32W>
 int launch_dwpw_xs(const DwPwArgs& a, hipStream_t s) {
-    constexpr int lds_bytes = S_LDS_P + XP_RING * XP_STEP;
+    constexpr int lds_bytes = S_LDS_P + XP_RING * FP_STEP;
     static_assert(lds_bytes <= 160 * 1024, "k_dwpw_xs LDS");
-    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw_xs<F32W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(k_dwpw_xs<F32W>, dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
+    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw_xs), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_dwpw_xs, dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
@@ -883,8 +821,9 @@ int validate_dwpw(const avl_seg_op& op) {
     AVL_REQUIRE(op.in && op.out && op.weight && op.bias && op.in2, "dwpw has NULL buffers");
     AVL_REQUIRE(!op.w_split || op.dtype == AVL_F16, "split weights need AVL_F16 activations");
     AVL_REQUIRE(!op.in2_lo && (!op.out_lo || op.w_split), "dwpw: the output may be split only with w_split");
-    AVL_REQUIRE(!op.in_lo || op.w_split >= 2, "dwpw: a split input (in_lo) needs the exact depthwise stage (w_split 2 or 3: k_dwpw_xs)");
-    AVL_REQUIRE(op.w_layout == 0 || (op.w_layout == 1 && op.in_lo && op.w_split >= 2), "dwpw: w_layout 1 (8 x 16-pixel tiles) exists for the split-input kernel only");
+    AVL_REQUIRE(op.w_split != 2, "dwpw: w_split 2 (f16 depthwise weight pairs) was replaced by w_split 3 (fp32 depthwise weights)");
+    AVL_REQUIRE(!op.in_lo || op.w_split == 3, "dwpw: a split input (in_lo) needs the exact depthwise stage (w_split 3: k_dwpw_xs)");
+    AVL_REQUIRE(op.w_layout == 0 || (op.w_layout == 1 && op.in_lo && op.w_split == 3), "dwpw: w_layout 1 (8 x 16-pixel tiles) exists for the split-input kernel only");
     AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.out_lo) | reinterpret_cast<uintptr_t>(op.in_lo)) % 16 == 0, "dwpw low planes must be 16-byte aligned");
     const int M = op.out_h * op.out_w, K = op.in_c, N = op.out_c;
     AVL_REQUIRE(op.stride == 1 && op.ksize == 3 && op.dil >= 1 && op.pad >= 0 && op.out_h == op.in_h + 2 * op.pad - 2 * op.dil &&
@@ -912,12 +851,11 @@ int launch_dwpw(const avl_seg_op& op, hipStream_t s) {
     const int mtiles = a.tiles_x > 0 ? a.tiles_x * ((op.out_h + 7) / 8) : (a.M + TM - 1) / TM;     // (the host's visiting order in2 has this many entries)
     a.mtiles = mtiles;
     a.per_xcd = (mtiles + 7) / 8;
-    a.order = reinterpret_cast<const int*>(a.dwp + (a.K / 64) * ((op.w_split == 3 ? FP_STEP : op.w_split == 2 ? XP_STEP : P_STEP) / 4));
+    a.order = reinterpret_cast<const int*>(a.dwp + (a.K / 64) * ((op.w_split == 3 ? FP_STEP : P_STEP) / 4));
     a.C_lo = op.out_lo;
-    // exact depthwise stage (split tile, three MFMA passes): w_split 3 = fp32 depthwise weights (pack_dw_f32), 2 = f16 weight pairs (pack_dw_pairs_split);
-    // with in_lo the input is two planes (the "mixed" decoder, the split16 ASPP)
-    if (op.w_split == 3) return op.in_lo ? launch_dwpw_xs<true>(a, s) : launch_dwpw_x<true>(a, s);
-    if (op.w_split == 2) return op.in_lo ? launch_dwpw_xs<false>(a, s) : launch_dwpw_x<false>(a, s);
+    // exact depthwise stage (fp32 depthwise weights: pack_dw_f32; split tile, three MFMA passes); with in_lo the input is two planes (the "mixed"
+    // decoder, the split16 ASPP)
+    if (op.w_split == 3) return op.in_lo ? launch_dwpw_xs(a, s) : launch_dwpw_x(a, s);
     if (op.w_split) return launch_dwpw_typed<f16, 2>(a, mtiles, s);
     return op.dtype == AVL_F16 ? launch_dwpw_typed<f16, 1>(a, mtiles, s) : launch_dwpw_typed<bf16, 1>(a, mtiles, s);
 }

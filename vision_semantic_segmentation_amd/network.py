@@ -251,29 +251,8 @@ def pack_gconv_mx(w, groups):
     return frag_hi, torch.cat([w4.reshape(-1), w4s.reshape(-1)])
 
 
-def pack_dw_pairs_split(w, b):
-    """Depthwise parameters for k_dwpw_x (w_split = 2 of AVL_OP_DWPW): w float64 [C][1][3][3] and b [C] (BN folded) -> int32
-    [C/64][chunk 8][11][8]: five tap pairs of the f16 HI parts of the weights (tap 2p in the low half, tap 2p+1 in the high half; the
-    ninth tap pairs with zero), the same five pairs of the f16 LO parts (w - hi), and the fp32 bias bits."""
-    c = w.shape[0]
-    assert c % 64 == 0
-    w9 = w.reshape(c, 9).to(torch.float64)
-    hi, lo = split_f16(w9)
-
-    def pairs(part):
-        w16 = torch.cat([part, torch.zeros((c, 1), dtype=torch.float16)], dim=1)                      # [C][10]
-        bits = w16.view(torch.int16).to(torch.int32) & 0xFFFF
-        return (bits[:, 0::2] | (bits[:, 1::2] << 16)).reshape(c // 64, 8, 8, 5).permute(0, 1, 3, 2)   # [step][chunk][pair][ch]
-
-    out = torch.empty((c // 64, 8, 11, 8), dtype=torch.int32)
-    out[:, :, 0:5, :] = pairs(hi)
-    out[:, :, 5:10, :] = pairs(lo)
-    out[:, :, 10, :] = b.to(torch.float32).view(torch.int32).reshape(c // 64, 8, 8)
-    return out.reshape(-1)
-
-
 def pack_dw_f32(w, b):
-    """Depthwise parameters for k_dwpw_xs<F32W> (w_split = 3 of AVL_OP_DWPW: split input, fp32 depthwise weights): w float64 [C][1][3][3]
+    """Depthwise parameters for the exact depthwise stage (w_split = 3 of AVL_OP_DWPW: k_dwpw_x, k_dwpw_xs; fp32 depthwise weights): w float64 [C][1][3][3]
     and b [C] (BN folded) -> the int32 bit patterns of float32 [C/64][chunk 8][row 10][8]: rows 0 .. 8 = tap t of the chunk's eight
     channels, row 9 = the bias."""
     c = w.shape[0]
