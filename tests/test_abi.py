@@ -44,6 +44,55 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.avl_project_pcd_scratch_bytes(1000) >= 4000
 
 
+def test_plan_validation_refuses_this_rounds_removed_and_restricted_forms():
+    """avl_seg_plan_create validates every op on the host (no GPU call): the fused depthwise op no longer takes f16 weight pairs
+    (w_split 2), block tiles (w_layout 1) exist for a split input only, and the classifier's fused arg-max (out_f32 + out_mx = labels)
+    needs N <= 32 and neither residual nor ReLU."""
+    import ctypes as C
+    import torch
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import OP_DWPW, OP_GEMM, AvlSegOp
+    buf = torch.zeros(1 << 16, dtype=torch.uint8)
+    ptr = (buf.data_ptr() + 255) // 256 * 256
+
+    def create(op):
+        plan = C.c_void_p()
+        rc = _lib.lib().avl_seg_plan_create((AvlSegOp * 1)(op), 1, C.byref(plan))
+        if rc == 0:
+            _lib.lib().avl_seg_plan_destroy(plan)
+        return rc, _lib.last_error()
+
+    op = AvlSegOp()
+    op.kind, op.dtype = OP_DWPW, _lib.AVL_F16
+    op.in_ = op.in2 = op.out = op.weight = op.bias = ptr
+    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = 8, 8, 64, 64, 64
+    op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = 8, 8, 256, 256, 256
+    op.relu, op.w_rows, op.ksize, op.stride, op.pad, op.dil, op.groups, op.w_split = 1, 256, 3, 1, 1, 1, 64, 2
+    rc, msg = create(op)
+    assert rc == -1 and "w_split 2" in msg and "w_split 3" in msg
+    op.w_split, op.w_layout = 3, 1
+    rc, msg = create(op)
+    assert rc == -1 and "w_layout 1" in msg
+    op.w_layout = 0
+    assert create(op)[0] == 0
+    op.in_lo, op.w_layout = ptr, 1
+    assert create(op)[0] == 0
+
+    g = AvlSegOp()
+    g.kind, g.dtype = OP_GEMM, _lib.AVL_F16
+    g.in_ = g.out = g.weight = g.bias = g.out_mx = ptr
+    g.in_h, g.in_w, g.in_c, g.in_ld, g.in_rows = 1, 256, 256, 256, 256
+    g.out_h, g.out_w, g.out_c, g.out_ld, g.out_rows = 1, 256, 19, 19, 256
+    g.out_f32, g.w_rows, g.ksize, g.stride, g.dil, g.groups = 1, 64, 1, 1, 1, 1
+    assert create(g)[0] == 0
+    g.relu = 1
+    rc, msg = create(g)
+    assert rc == -1 and "arg-max" in msg
+    g.relu, g.out_c, g.out_ld = 0, 48, 48
+    rc, msg = create(g)
+    assert rc == -1 and "arg-max" in msg
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from vision_semantic_segmentation_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
