@@ -397,8 +397,9 @@ def test_mixed_logits_within_1e3_of_oracle(state, hw, cuda_device):
     assert agree >= 0.998
 
 
-# weight seeds 0-3 x 2 frames at 480 x 640, weight seeds 0 and 2 (the worst draw of tools/seed_sweep.py) on the bench frame
-SEED_CASES = [(ws, 30 + 2 * ws + i, 480, 640) for ws in range(4) for i in range(2)] + [(0, "bench", 1080, 1920), (2, "bench", 1080, 1920)]
+# weight seeds 0-3 x one frame at 480 x 640 (two frames each until round 5: the suite took 526 s on one of the pool's slow boxes; the 28-combination
+# sweep is tools/seed_sweep.py, profiles/r04/seed_sweep.log), weight seeds 0 and 2 (the worst draw of that sweep) on the bench frame
+SEED_CASES = [(ws, 30 + 2 * ws + 1, 480, 640) for ws in range(4)] + [(0, "bench", 1080, 1920), (2, "bench", 1080, 1920)]
 
 
 @pytest.mark.parametrize("wseed,iseed,h,w", SEED_CASES)

@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(512) k_dwpw_x(DwPwArgs p) {
     const int mt = p.order[slot];
     const int nk = p.K / 64;
 
-    // ---- depthwise parameters: K-step s -> ring slot s & 3, 176 lanes x 16 bytes
+    // ---- depthwise parameters: K-step s -> ring slot s & 3, 160 lanes x 16 bytes
     const uint4* psrc = reinterpret_cast<const uint4*>(p.dwp);
     uint4 pnext = make_uint4(0u, 0u, 0u, 0u);
     auto load_p = [&](int s) { if (tid < PSTEP / 16 && s < nk) pnext = psrc[s * (PSTEP / 16) + tid]; };
@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
     const int nk = p.K / 64;
 
     const unsigned lds0 = lds_addr(lds);
-    // ---- depthwise parameters: K-step s -> ring slot s & 3; 2816 bytes = 176 lanes x 16 bytes, by LDS-DMA (waves 0 .. 2)
+    // ---- depthwise parameters: K-step s -> ring slot s & 3; 2560 bytes = 160 lanes x 16 bytes, by LDS-DMA (waves 0 .. 2)
     auto dma_p = [&](int s) {
         if (tid < PSTEP / 16 && s < nk)
             glds16_saddr(reinterpret_cast<const char*>(p.dwp) + s * PSTEP, (unsigned)tid * 16u, lds0 + S_LDS_P + (s & (XP_RING - 1)) * PSTEP + wave * 1024);
