@@ -454,7 +454,7 @@ def test_mixed_logits_with_layer1_lo_planes(state, cuda_device):
     from test_gpu_seg import _cfg
     from vision_semantic_segmentation_amd import SemanticSegmentation
     cfg = _cfg("mixed")
-    assert cfg.MODEL.MIXED_LAYER1_LO is False
+    assert cfg.MODEL.MIXED_LAYER1_LO is True
     img = np.random.default_rng(0).integers(0, 256, size=(320, 416, 3), dtype=np.uint8)
     ref = no.forward_logits(state, img)[0]
     errs, los = [], []

@@ -102,8 +102,9 @@ def get_network_cfg_defaults():
                                         # -5 % frames/s; False was the round-2 default, whose error passed 1e-3 on one weights draw in four (profiles/r02/seed_sweep.log)
     C.MODEL.MIXED_TRUNK_FP4 = True      # "mixed" only: keep the lo part of the residual trunk / 3x3 outputs as FP4 only (False: f16 lo planes, 12 % slower, -0..14 % error)
     C.MODEL.MIXED_CONV2_SPLIT = True    # "mixed" only: keep every bottleneck's 3x3 output as hi + lo (conv3 corrects for both parts)
-    C.MODEL.MIXED_LAYER1_LO = False     # "mixed" only: True = layer1's first two blocks keep a lo plane of their output as well (the last block always does):
-                                        # -10..-30 % logits error (worst draw 7.3e-4 instead of 8.2e-4 at 1080p) for +0.4 GB of HBM traffic per frame (-2.5 % frames/s)
+    C.MODEL.MIXED_LAYER1_LO = True      # "mixed" only: every block of layer1 keeps a lo plane of its output (default since the end of round 5: with layer1's blocks
+                                        # fused the planes cost 0.03 ms per frame and the worst measured 1080p logits error is 7.3e-4 instead of 8.8e-4,
+                                        # profiles/r05/seed_sweep.log); False = the first two blocks write ONE f16 plane (the self-check ladder's "mixed" rung)
     C.MODEL.MIXED_SELF_CHECK = "auto"   # "mixed" only: before the first plan, measure a ladder of plans (mixed -> + layer1 lo planes -> all-f16 split ->
                                         # f32) against the fp32-input HIP path on four seeded frames, scan every 16-bit tensor for Inf / NaN, and keep the
                                         # first plan within 1e-3 (SemanticSegmentation.check_mixed_against_f32).  "auto" = when MODEL.WEIGHT names a

@@ -533,10 +533,11 @@ class SegNet(object):
         self.mixed_fuse_ds = mixed_opts.get("fuse_ds", True)     # stride-1 downsample folded into conv3 (second input along K)
         self.mixed_fuse_decoder = mixed_opts.get("fuse_decoder", True)   # the decoder's refine blocks as one k_dwpw_xs launch each (split input)
         self.mixed_dw_exact = mixed_opts.get("dw_exact", True)    # fused depthwise+pointwise (ASPP) with split depthwise weights and a split depthwise result (k_dwpw_x)
-        # layer1_lo = False (default): the first two blocks of layer1 write a SINGLE f16 trunk plane (the last one keeps hi + lo: the
-        # decoder's low-level branch and layer2 read it).  layer1's GEMMs are HBM-bound (K = 128 / 256 at 129 600 pixels): the lo planes
-        # are 0.4 GB of the frame's traffic = 2.5 % of its time, for -10...-30 % logits error (8.2e-4 -> 7.3e-4 on the worst draw)
-        self.mixed_layer1_lo = mixed_opts.get("layer1_lo", False)
+        # layer1_lo = True (default since the end of round 5): every block of layer1 keeps the lo plane of its output.  False: the first two
+        # blocks write a SINGLE f16 trunk plane (the last one keeps hi + lo: the decoder's low-level branch and layer2 read it) -- round 3's
+        # trade when layer1's GEMMs were separate HBM-bound launches (0.4 GB of traffic = 2.5 % of the frame for -10...-30 % logits error);
+        # with the blocks fused the planes cost 0.03 ms (0.6 %) and the worst 1080p draw measures 7.3e-4 instead of 8.8e-4
+        self.mixed_layer1_lo = mixed_opts.get("layer1_lo", True)
         # fuse_block (default): every Bottleneck of layer1 is ONE kernel (AVL_OP_BOTTLENECK: conv1 -> grouped 3x3 -> conv3 + residual with
         # both intermediates in LDS); False = the three-launch form of rounds 1-4
         self.mixed_fuse_block = self.mixed and mixed_opts.get("fuse_block", True)

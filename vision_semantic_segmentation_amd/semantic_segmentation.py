@@ -56,14 +56,14 @@ class SemanticSegmentation(object):
         # draws only, so a real checkpoint is checked once, before its first plan, against the fp32-input HIP path (itself 2e-6 from
         # the fp32 reference) on several seeded frames, and every 16-bit tensor of the plan is scanned for Inf / NaN where it is
         # produced.  The check walks a LADDER of plans and keeps the first one that passes:
-        #   "mixed"       as configured (f16 + FP4 matrix cores)
-        #   "mixed+lo"    + MIXED_LAYER1_LO (every layer1 block keeps its lo plane)
+        #   "mixed"       f16 + FP4 matrix cores, layer1's first two blocks write one f16 plane (MIXED_LAYER1_LO = False starts here)
+        #   "mixed+lo"    every layer1 block keeps its lo plane (the default configuration starts here)
         #   "split16"     the COMPLETE hi + lo pipeline (SegNet(full_split=True)): every tensor two f16 planes, every product three f16 passes, no
         #                 FP4 and no single-plane tensor anywhere -- what a calibrated (trained) checkpoint needs
         #   "f32"         fp32-input MFMA, the reference's precision (50 frames/s)
         sc = getattr(cfg.MODEL, "MIXED_SELF_CHECK", "auto")
         self._self_check = (state_dict is None and bool(cfg.MODEL.WEIGHT)) if sc == "auto" else _strict_bool(sc, "MODEL.MIXED_SELF_CHECK")
-        self._layer1_lo = bool(getattr(cfg.MODEL, "MIXED_LAYER1_LO", False))
+        self._layer1_lo = bool(getattr(cfg.MODEL, "MIXED_LAYER1_LO", True))
         self._rung = "mixed+lo" if self._layer1_lo else "mixed"     # which plan of the ladder the "mixed" precision currently means
         self.on_fail = str(getattr(cfg.MODEL, "MIXED_ON_FAIL", "f32"))
         if self.on_fail not in ("f32", "raise", "warn"):
