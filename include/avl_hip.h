@@ -247,6 +247,11 @@ int avl_eval_map(const uint8_t* color_map, int H, int W, const uint8_t* mask, in
                                 8-channel chunk: rows 0 .. 8 = tap t of the chunk's eight channels, row 9 = the bias; then the
                                 tile order as above.  `weight` is the 1x1 conv's [n][K/64][hi 64 | lo 64] as for w_split = 1.
                                 (w_split = 2 -- depthwise weights as f16 pairs, rounds 3-5 -- is no longer accepted.)
+                                With out_f32 (split input, w_split = 3, out_c = 256): the network's LAST 1x1 conv (decoder.py:42-43:
+                                256 -> in3_c <= 32 classes, bias, no BN / ReLU) and torch.argmax (semantic_segmentation.py:56) run in the
+                                epilogue on the block's result, which is never written: in3 = classifier weights f16 [hi | lo][32][256]
+                                (rows >= in3_c zero), in2_lo = fp32 bias[32], out = fp32 logits [rows][in3_c] (out_ld = in3_c),
+                                out_mx = uint8 labels[rows].
                                 With in_lo (w_split = 3): the input is two f16 planes (the "mixed" decoder's refine blocks,
                                 decoder.py:33-43; the ASPP branches of the complete hi + lo plan).  w_layout = 1 (with in_lo):
                                 a tile is an 8 x 16 block of output pixels instead of 128 consecutive ones; the order array

@@ -289,6 +289,71 @@ def test_exact_fused_depthwise_pointwise_with_a_split_input(case, cuda_device):
     assert float((got - ref_hi).abs().max() / ref.abs().max()) > 10 * err
 
 
+@pytest.mark.parametrize("case", [(37, 53, 256, 19, 1), (20, 31, 512, 19, 0), (11, 70, 64, 32, 1), (9, 140, 128, 5, 0)])
+def test_fused_depthwise_pointwise_with_the_classifier_in_its_epilogue(case, cuda_device):
+    """round 5: AVL_OP_DWPW with out_f32 (k_dwpw_xs<CLS>): the decoder's last refine block (decoder.py:38-41), the classifier (decoder.py:42-43:
+    1x1 conv with bias, no BN / ReLU) and torch.argmax (semantic_segmentation.py:56) in ONE launch -- the block's 256-channel result exists only
+    in LDS, as f16 hi + lo tiles.  Logits against a float64 evaluation of the same operands; labels = the arg-max of the logits the kernel wrote,
+    first maximal index on ties (classes 1 and 3 get identical weights and win everywhere they can)."""
+    import torch
+    import torch.nn.functional as F
+    from test_gpu_ops import _nhwc_rows
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import OP_DWPW, AvlSegOp, dwpw_block_order, dwpw_tile_order, pack_dw_f32, pack_split_rows, split_f16
+    H, W, K, ncls, blocks = case
+    N, d, pad = 256, 1, 0
+    OH, OW = H - 2, W - 2
+    g = torch.Generator().manual_seed(H * 31 + W + K + ncls)
+    x = torch.randn((1, K, H, W), generator=g, dtype=torch.float64)
+    xh, xl = _split(x)
+    w1 = (torch.randn((K, 1, 3, 3), generator=g) * 0.3).double()
+    b1 = (torch.randn(K, generator=g) * 0.1).double()
+    w2 = torch.randn((N, K), generator=g, dtype=torch.float64) / K ** 0.5
+    b2 = torch.randn(N, generator=g) * 0.1
+    wc = torch.randn((ncls, N), generator=g, dtype=torch.float64) / N ** 0.5
+    bc = torch.randn(ncls, generator=g, dtype=torch.float64) * 0.1
+    if ncls > 3:
+        wc[3], bc[3] = wc[1], bc[1]
+        bc[1] = bc[3] = 3.0                       # the tied pair is the maximum on most pixels
+    M = OH * OW
+    Mp = (M + 255) // 256 * 256
+    src = torch.stack([_nhwc_rows(xh), _nhwc_rows(xl)]).to(cuda_device)
+    w2d, b2d = pack_split_rows(w2, 2).to(cuda_device), b2.to(cuda_device)
+    wc32 = torch.zeros((32, N), dtype=torch.float64)
+    wc32[:ncls] = wc
+    bc32 = torch.zeros(32)
+    bc32[:ncls] = bc.float()
+    wch, wcl = split_f16(wc32)
+    wcd, bcd = torch.stack([wch, wcl]).to(cuda_device), bc32.to(cuda_device)
+    logits = torch.full((Mp, ncls), -7.0, dtype=torch.float32, device=cuda_device)
+    labels = torch.full((Mp,), 99, dtype=torch.uint8, device=cuda_device)
+    params = torch.cat([pack_dw_f32(w1, b1), dwpw_block_order(OH, OW) if blocks else dwpw_tile_order(OH, OW, d)]).to(cuda_device)
+    op = AvlSegOp()
+    op.kind, op.dtype = OP_DWPW, _lib.AVL_F16
+    op.in_, op.in_lo, op.in2, op.in2_lo, op.in3, op.in3_c = src[0].data_ptr(), src[1].data_ptr(), params.data_ptr(), bcd.data_ptr(), wcd.data_ptr(), ncls
+    op.out, op.out_mx, op.out_f32 = logits.data_ptr(), labels.data_ptr(), 1
+    op.weight, op.bias, op.w_split, op.w_layout = w2d.data_ptr(), b2d.data_ptr(), 3, blocks
+    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = H, W, K, K, src.shape[1]
+    op.out_h, op.out_w, op.out_c, op.out_ld, op.out_rows = OH, OW, N, ncls, Mp
+    op.relu, op.w_rows, op.ksize, op.stride, op.pad, op.dil, op.groups = 1, 256, 3, 1, pad, d, K
+    _run_plan([op])
+    a64 = F.relu(F.conv2d(xh.double() + xl.double(), w1.float().double(), b1.float().double(), groups=K))
+    ah, al = _split(a64)
+    w_hi, w_lo = _split(w2)
+    y64 = F.relu(F.conv2d(ah.double() + al.double(), (w_hi.double() + w_lo.double()).view(N, K, 1, 1), b2.double()))
+    yh, yl = _split(y64)
+    ref = F.conv2d(yh.double() + yl.double(), (wch.double() + wcl.double())[:ncls].view(ncls, N, 1, 1), bc.float().double())[0]      # [ncls, OH, OW]
+    got = logits[:M].cpu().double().t().reshape(ncls, OH, OW)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print("dwpw + classifier %s: %.3e" % (case, err))
+    assert err <= 2 * TOL, "dwpw + classifier %s: %.3e" % (case, err)
+    lab = labels[:M].cpu().long()
+    assert torch.equal(lab, torch.argmax(logits[:M].cpu(), dim=1))
+    if ncls > 3:
+        assert int((lab == 1).sum()) > M // 2 and int((lab == 3).sum()) == 0 and bool((logits[:M, 1] == logits[:M, 3]).all())
+    assert torch.all(labels[M:] == 99) and torch.all(logits[M:] == -7.0)
+
+
 @pytest.mark.parametrize("case", [(37, 53, 64, 1, 0), (20, 31, 512, 1, 0), (9, 9, 64, 2, 2)])
 def test_split_depthwise_and_bilinear(case, cuda_device):
     import torch

@@ -36,6 +36,13 @@ constexpr int P_STEP = 8 * 6 * 8 * 4;                                         //
 struct DwPwArgs {
     const void* X;
     const void* X_lo;        // k_dwpw_xs: low plane of the input (same row stride), else NULL
+    // k_dwpw_xs<CLS>: the network's last 1x1 conv (decoder.py:42-43: 256 -> num_classes, bias, no BN / ReLU) and torch.argmax (semantic_segmentation.py:56)
+    // in this kernel's epilogue -- the block's own result never goes to memory
+    const void* Wc;          // classifier weights, f16 [2 planes hi | lo][32 rows][N]
+    const float* bc;         // its bias [32]
+    float* LG;               // logits [M][ncls]
+    unsigned char* labels;   // arg-max [M]
+    int ncls;
     int tiles_x;             // k_dwpw_xs: > 0 = the 128 pixels of a tile are an 8 x 16 block (tile mt = (mt / tiles_x, mt % tiles_x)) instead of 128 consecutive pixels
     const void* W;
     const float* bias;
@@ -522,6 +529,7 @@ int launch_dwpw_x(const DwPwArgs& a, hipStream_t s) {
 //   weight sub-slices and depthwise parameters come by LDS-DMA (no staging registers: 246 VGPRs).
 //   LDS: weight ring 2 x 32 KB | hi tiles 2 x 16 KB | lo tiles 2 x 16 KB | parameter ring 4 x 2.5 KB = 138 KB.
 constexpr int S_LDS_W = 0, S_LDS_AH = 2 * W_STAGE, S_LDS_AL = S_LDS_AH + 2 * A_STAGE, S_LDS_P = S_LDS_AL + 2 * A_STAGE;
+template <bool CLS>
 __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
     constexpr int PSTEP = FP_STEP;          // bytes of depthwise parameters per K-step
     typedef f16 HT;
@@ -763,6 +771,94 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
     int elane = lane;
     asm volatile("" : "+v"(elane));
     const int efr = elane & 15;
+    if constexpr (CLS) {
+        // ---- the classifier on this tile's 128 x 256 result.  (1) ReLU, hi / lo split, into LDS as four 64-channel A tiles per plane (hi at 0
+        // over the weight ring, lo at 64 KB over the depthwise tiles: both are done with), in the layout the fragment reads above use;
+        // (2) wave w takes pixels 16 w .. 16 w + 15: logits[class][pixel] = Wc . y in three passes (Wh.yl, Wl.yh, Wh.yh), weights straight
+        // from L2 (32 KB); (3) a lane ends with classes 4 kq .. + 3 and 16 + 4 kq .. + 3 of pixel fr: fp32 logits out, arg-max across the
+        // four lanes of a pixel (first maximal index wins, a NaN counts as maximal, as torch.argmax)
+        const int ekq = elane >> 4;
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int row = wm * 64 + mi * 16 + efr;
+            float v0[8], v1[8], l0[8], l1[8];
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v0[nj * 4 + r] = fmaxf(acc[mi][nj][r], 0.f);
+                    v1[nj * 4 + r] = fmaxf(acc[mi][2 + nj][r], 0.f);
+                }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { l0[i] = v0[i] - (float)(HT)v0[i]; l1[i] = v1[i] - (float)(HT)v1[i]; }
+            const int base = wn * A_STAGE + row * 128;
+            const int o0 = base + (((2 * ekq) ^ (row & 7)) << 4), o1 = base + (((2 * ekq + 1) ^ (row & 7)) << 4);
+            Vec8<HT>::store(reinterpret_cast<HT*>(lds + o0), v0);
+            Vec8<HT>::store(reinterpret_cast<HT*>(lds + o1), v1);
+            Vec8<HT>::store(reinterpret_cast<HT*>(lds + 65536 + o0), l0);
+            Vec8<HT>::store(reinterpret_cast<HT*>(lds + 65536 + o1), l1);
+        }
+        __syncthreads();
+        f32x4 a2[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bc + t2 * 16 + 4 * ekq);
+            a2[t2] = f32x4{b.x, b.y, b.z, b.w};
+        }
+        const int crow = wave * 16 + efr;
+        const char* wcl = static_cast<const char*>(p.Wc) + ((long long)efr * p.N + ekq * 8) * 2;          // + (t2 * 16 rows, K offset) ; lo plane 32 rows further
+        const long long wplane = 32LL * p.N * 2;
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int off = st * A_STAGE + crow * 128 + (((kk * 4 + ekq) ^ (efr & 7)) << 4);
+                const v8 yh = *reinterpret_cast<const v8*>(lds + off), yl = *reinterpret_cast<const v8*>(lds + 65536 + off);
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const char* wp = wcl + ((long long)t2 * 16 * p.N + st * 64 + kk * 32) * 2;
+                    const v8 wh = *reinterpret_cast<const v8*>(wp), wl = *reinterpret_cast<const v8*>(wp + wplane);
+                    a2[t2] = Half16<HT>::mfma(wh, yl, a2[t2]);
+                    a2[t2] = Half16<HT>::mfma(wl, yh, a2[t2]);
+                    a2[t2] = Half16<HT>::mfma(wh, yh, a2[t2]);
+                }
+            }
+        // pixel of this lane
+        int m;
+        {
+            const int ml = crow;
+            if (p.tiles_x > 0) {
+                const int y = tty * 8 + (ml >> 4), x = ttx * 16 + (ml & 15);
+                m = ((y < OHt) & (x < p.OW)) ? y * p.OW + x : p.M;
+            } else {
+                m = mt * TM + ml;
+            }
+        }
+        float best = a2[0][0];
+        int bi = 4 * ekq;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cls = t2 * 16 + 4 * ekq + r;
+                const float v = a2[t2][r];
+                if (cls < p.ncls) {
+                    if (m < p.M) p.LG[(long long)m * p.ncls + cls] = v;
+                    if ((t2 | r) && (v > best || (v != v && best == best))) { best = v; bi = cls; }
+                }
+            }
+#pragma unroll
+        for (int sh = 16; sh <= 32; sh <<= 1) {
+            const float ov = __shfl_xor(best, sh, 64);
+            const int oi = __shfl_xor(bi, sh, 64);
+            const bool onan = ov != ov, bnan = best != best;
+            const bool take = onan ? (!bnan || oi < bi) : (!bnan && (ov > best || (ov == best && oi < bi)));
+            if (take) { best = ov; bi = oi; }
+        }
+        if (ekq == 0 && m < p.M) p.labels[m] = (unsigned char)bi;
+        return;
+    }
     const int nbase = nt * TN + wn * 64 + (elane >> 4) * 16;
     if (nbase + 16 <= p.N) {
 #pragma unroll
@@ -796,11 +892,12 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
     }
 }
 
+template <bool CLS>
 int launch_dwpw_xs(const DwPwArgs& a, hipStream_t s) {
     constexpr int lds_bytes = S_LDS_P + XP_RING * FP_STEP;
-    static_assert(lds_bytes <= 160 * 1024, "k_dwpw_xs LDS");
-    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw_xs), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(k_dwpw_xs, dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
+    static_assert(lds_bytes <= 160 * 1024 && S_LDS_AH == 65536 && 4 * A_STAGE == 65536, "k_dwpw_xs LDS (the classifier epilogue keeps y hi at 0 and y lo at 64 KB, 64 KB each)");
+    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwpw_xs<CLS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_dwpw_xs<CLS>, dim3(8 * a.per_xcd * a.ntiles), dim3(512), lds_bytes, s, a);
     AVL_LAUNCH_CHECK();
     return AVL_OK;
 }
@@ -820,7 +917,13 @@ int validate_dwpw(const avl_seg_op& op) {
     AVL_REQUIRE(is_half(op.dtype), "fused depthwise+pointwise needs a 16-bit activation type");
     AVL_REQUIRE(op.in && op.out && op.weight && op.bias && op.in2, "dwpw has NULL buffers");
     AVL_REQUIRE(!op.w_split || op.dtype == AVL_F16, "split weights need AVL_F16 activations");
-    AVL_REQUIRE(!op.in2_lo && (!op.out_lo || op.w_split), "dwpw: the output may be split only with w_split");
+    AVL_REQUIRE((!op.in2_lo || op.out_f32) && (!op.out_lo || op.w_split), "dwpw: the output may be split only with w_split (in2_lo: the classifier's bias, with out_f32 only)");
+    if (op.out_f32) {
+        AVL_REQUIRE(op.w_split == 3 && op.in_lo && !op.out_lo && op.out_c == TN && op.in3 && op.in2_lo && op.out_mx && op.in3_c >= 1 && op.in3_c <= 32 && op.out_ld == op.in3_c,
+                    "dwpw with out_f32 (classifier + arg-max in the epilogue): needs a split input, w_split 3, out_c 256, in3 = f16 [2][32][256] weights, in2_lo = "
+                    "fp32 bias[32], out = fp32 logits [rows][in3_c <= 32] (out_ld = in3_c), out_mx = uint8 labels[rows], no out_lo");
+        AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.in3) | reinterpret_cast<uintptr_t>(op.in2_lo)) % 16 == 0 && reinterpret_cast<uintptr_t>(op.out) % 4 == 0, "dwpw classifier operands unaligned");
+    }
     AVL_REQUIRE(op.w_split != 2, "dwpw: w_split 2 (f16 depthwise weight pairs) was replaced by w_split 3 (fp32 depthwise weights)");
     AVL_REQUIRE(!op.in_lo || op.w_split == 3, "dwpw: a split input (in_lo) needs the exact depthwise stage (w_split 3: k_dwpw_xs)");
     AVL_REQUIRE(op.w_layout == 0 || (op.w_layout == 1 && op.in_lo && op.w_split == 3), "dwpw: w_layout 1 (8 x 16-pixel tiles) exists for the split-input kernel only");
@@ -832,7 +935,7 @@ int validate_dwpw(const avl_seg_op& op) {
     AVL_REQUIRE(K % 64 == 0 && K <= 2048, "dwpw K = %d (multiple of 64, <= 2048: the depthwise parameters live in LDS)", K);
     AVL_REQUIRE(N % 16 == 0 && op.w_rows >= (N + TN - 1) / TN * TN, "dwpw N = %d / weight rows %d", N, op.w_rows);
     AVL_REQUIRE(op.in_ld >= K && (op.in_ld * 2) % 16 == 0, "dwpw in_ld %d", op.in_ld);
-    AVL_REQUIRE(op.out_ld >= N && (op.out_ld * 2) % 16 == 0, "dwpw out_ld %d", op.out_ld);
+    if (!op.out_f32) AVL_REQUIRE(op.out_ld >= N && (op.out_ld * 2) % 16 == 0, "dwpw out_ld %d", op.out_ld);
     AVL_REQUIRE(op.in_rows >= op.in_h * op.in_w && op.out_rows >= M, "dwpw rows");
     AVL_REQUIRE((long long)op.in_rows * op.in_ld * 2 < 0x7fffff00LL, "dwpw input larger than a buffer descriptor's range");
     AVL_REQUIRE((reinterpret_cast<uintptr_t>(op.in) | reinterpret_cast<uintptr_t>(op.weight) | reinterpret_cast<uintptr_t>(op.out) |
@@ -843,6 +946,7 @@ int validate_dwpw(const avl_seg_op& op) {
 int launch_dwpw(const avl_seg_op& op, hipStream_t s) {
     DwPwArgs a;
     a.X = op.in; a.X_lo = op.in_lo; a.W = op.weight;
+    a.Wc = nullptr; a.bc = nullptr; a.LG = nullptr; a.labels = nullptr; a.ncls = 0;
     a.tiles_x = (op.w_layout == 1) ? (op.out_w + 15) / 16 : 0; a.bias = op.bias; a.dwp = static_cast<const uint32_t*>(op.in2); a.C = op.out;
     a.H = op.in_h; a.Wd = op.in_w; a.OW = op.out_w; a.ldx = op.in_ld; a.ldc = op.out_ld; a.pad = op.pad;
     a.M = op.out_h * op.out_w; a.N = op.out_c; a.K = op.in_c; a.dil = op.dil;
@@ -855,7 +959,12 @@ int launch_dwpw(const avl_seg_op& op, hipStream_t s) {
     a.C_lo = op.out_lo;
     // exact depthwise stage (fp32 depthwise weights: pack_dw_f32; split tile, three MFMA passes); with in_lo the input is two planes (the "mixed"
     // decoder, the split16 ASPP)
-    if (op.w_split == 3) return op.in_lo ? launch_dwpw_xs(a, s) : launch_dwpw_x(a, s);
+    if (op.w_split == 3 && op.out_f32) {         // + the classifier and the arg-max in the epilogue (validate_dwpw)
+        a.Wc = op.in3; a.bc = static_cast<const float*>(op.in2_lo); a.LG = static_cast<float*>(op.out); a.labels = static_cast<unsigned char*>(op.out_mx);
+        a.ncls = op.in3_c;
+        return launch_dwpw_xs<true>(a, s);
+    }
+    if (op.w_split == 3) return op.in_lo ? launch_dwpw_xs<false>(a, s) : launch_dwpw_x(a, s);
     if (op.w_split) return launch_dwpw_typed<f16, 2>(a, mtiles, s);
     return op.dtype == AVL_F16 ? launch_dwpw_typed<f16, 1>(a, mtiles, s) : launch_dwpw_typed<bf16, 1>(a, mtiles, s);
 }

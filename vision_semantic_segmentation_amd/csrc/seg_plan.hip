@@ -78,6 +78,10 @@ void work(const avl_seg_op& op, double& flops, double& bytes) {
         case AVL_OP_DWPW:
             flops = 2.0 * out_pix * op.in_c * 9 + 2.0 * out_pix * op.out_c * op.in_c;
             bytes += (double)op.out_c * op.in_c * es;
+            if (op.out_f32) {      // the classifier + arg-max in the epilogue: the block's own result is never written; fp32 logits and uint8 labels are
+                flops += 2.0 * out_pix * op.out_c * op.in3_c;
+                bytes += out_pix * (op.in3_c * 4.0 + 1.0) - out_pix * op.out_c * e_out;
+            }
             break;
         case AVL_OP_BILINEAR:
             flops = 8.0 * out_pix * op.out_c;
@@ -239,7 +243,7 @@ extern "C" int avl_seg_plan_nonfinite(avl_seg_plan* plan, void* stream, unsigned
         if (op.kind == AVL_OP_ARGMAX) continue;                 // uint8 labels
         const long long rows = (op.kind == AVL_OP_GAP || op.kind == AVL_OP_GEMV) ? 1 : (long long)op.out_h * op.out_w;
         const bool f32 = op.dtype == AVL_F32 || op.out_f32 || op.kind == AVL_OP_GAP || op.kind == AVL_OP_GEMV;
-        if (f32) avl::count_plane<float>(op.out, rows, op.out_c, op.out_ld, dev + i, s);
+        if (f32) avl::count_plane<float>(op.out, rows, (op.kind == AVL_OP_DWPW && op.out_f32) ? op.in3_c : op.out_c, op.out_ld, dev + i, s);
         else if (op.dtype == AVL_F16) {
             avl::count_plane<avl::f16>(op.out, rows, op.out_c, op.out_ld, dev + i, s);
             avl::count_plane<avl::f16>(op.out_lo, rows, op.out_c, op.out_ld, dev + i, s);

@@ -500,7 +500,7 @@ class SegNet(object):
     native plan.  ``forward(image_u8_cuda)`` runs it; ``labels`` / ``logits`` are views of its outputs."""
 
     ROW_PAD = 256        # GEMM tiles read whole 128/256-row tiles
-    MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx", "dw_exact", "layer1_lo", "fuse_block", "full_split", "fuse_decoder")    # keyword switches of the "mixed" mode
+    MIXED_OPTS = ("conv1_split", "conv2_split", "mx", "trunk_fp4", "fuse_ds", "gconv_mx", "dw_exact", "layer1_lo", "fuse_block", "full_split", "fuse_decoder", "fuse_classifier")    # keyword switches of the "mixed" mode
 
     def __init__(self, state, height, width, precision="bf16", device=None, num_classes=19, output_stride=8, fuse_dwpw=True, raw_frame=None,
                  part=None, **mixed_opts):
@@ -531,6 +531,7 @@ class SegNet(object):
         self.mixed_mx = self.mixed and mixed_opts.get("mx", True)
         self.mixed_trunk_fp4 = mixed_opts.get("trunk_fp4", True)
         self.mixed_fuse_ds = mixed_opts.get("fuse_ds", True)     # stride-1 downsample folded into conv3 (second input along K)
+        self.mixed_fuse_classifier = mixed_opts.get("fuse_classifier", True)   # the classifier + arg-max in the last refine block's epilogue (k_dwpw_xs<CLS>)
         self.mixed_fuse_decoder = mixed_opts.get("fuse_decoder", True)   # the decoder's refine blocks as one k_dwpw_xs launch each (split input)
         self.mixed_dw_exact = mixed_opts.get("dw_exact", True)    # fused depthwise+pointwise (ASPP) with split depthwise weights and a split depthwise result (k_dwpw_x)
         # layer1_lo = True (default since the end of round 5): every block of layer1 keeps the lo plane of its output.  False: the first two
@@ -724,8 +725,10 @@ class SegNet(object):
                  out_c=cout, out_ld=old, out_rows=orows, ksize=3, stride=1, pad=1, dil=1, groups=GROUPS, relu=1, w_layout=int(wd is not None),
                  w_split=int(wd is not None))
 
-    def _dwpw(self, name, src, hw, cin, w_dw, b_dw, w_pw, b_pw, dst, dst_col, dilation, padding=None):
-        """DepthwiseSeparableConv2d (3x3 depthwise dil d pad p + BN + ReLU, 1x1 + BN + ReLU) as one op."""
+    def _dwpw(self, name, src, hw, cin, w_dw, b_dw, w_pw, b_pw, dst, dst_col, dilation, padding=None, classifier=None):
+        """DepthwiseSeparableConv2d (3x3 depthwise dil d pad p + BN + ReLU, 1x1 + BN + ReLU) as one op.  classifier = (w [K][cout] float64, b [K],
+        logits fp32 [rows][K], labels uint8 [rows]): the network's last 1x1 conv and the arg-max run in the kernel's epilogue (split input, cout = 256,
+        K <= 32); dst is then not written (None)."""
         h, wd = hw
         padding = dilation if padding is None else padding
         oh, ow = h + 2 * padding - 2 * dilation, wd + 2 * padding - 2 * dilation
@@ -746,6 +749,21 @@ class SegNet(object):
         params = torch.cat([dwp, dwpw_block_order(oh, ow) if blocks else dwpw_tile_order(oh, ow, dilation)]).to(self.device)
         self._keep.append(params)
         ip, ild, irows = self._view(src)
+        if classifier is not None:
+            wc, bc, logits, labels = classifier
+            ncls = wc.shape[0]
+            assert in_lo and cout == 256 and ncls <= 32 and wc.shape[1] == cout
+            wc32 = torch.zeros((32, cout), dtype=torch.float64)
+            wc32[:ncls] = wc
+            bc32 = torch.zeros(32, dtype=torch.float64)
+            bc32[:ncls] = bc
+            wcd = self._dev(torch.stack(split_f16(wc32)), torch.float16)           # [hi | lo][32][cout]
+            bcd = self._dev(bc32, torch.float32)
+            self._op(name, OP_DWPW, in_=ip, in_lo=in_lo, in2=params.data_ptr(), in2_lo=bcd.data_ptr(), in3=wcd.data_ptr(), in3_c=ncls, out=logits.data_ptr(),
+                     out_mx=labels.data_ptr(), out_f32=1, weight=wdev.data_ptr(), bias=bdev.data_ptr(), in_h=h, in_w=wd, in_c=cin, in_ld=ild, in_rows=irows,
+                     out_h=oh, out_w=ow, out_c=cout, out_ld=ncls, out_rows=logits.shape[0], relu=1, w_rows=w_rows, ksize=3, stride=1, pad=padding,
+                     dil=dilation, groups=cin, w_split=3, w_layout=int(blocks))
+            return
         op_, old, orows = self._view(dst, dst_col)
         self._op(name, OP_DWPW, in_=ip, in_lo=in_lo, in2=params.data_ptr(), out=op_, weight=wdev.data_ptr(), bias=bdev.data_ptr(), in_h=h, in_w=wd,
                  in_c=cin, in_ld=ild, in_rows=irows, out_h=oh, out_w=ow, out_c=cout, out_ld=old, out_rows=orows, relu=1, w_rows=w_rows,
@@ -1046,6 +1064,22 @@ class SegNet(object):
             ohw = (hw[0] - 2, hw[1] - 2)                                # padding 0 (decoder.py:33-36 default)
             w, b = fold_bn(st, p + ".depthwise_cnn.conv.weight", p + ".depthwise_cnn.bn")
             w2, b2 = fold_bn(st, p + ".pointwise_cnn.conv.weight", p + ".pointwise_cnn.bn")
+            last = ("decoder.refine_layers.%d.depthwise_cnn.conv.weight" % (k + 1)) not in st
+            fused_mixed = self.mixed and self.mixed_fuse_decoder and self.mixed_dw_exact
+            # the last refine block also carries the classifier (decoder.py:42-43) and the arg-max in its epilogue: its 256-channel result never goes to memory
+            if (last and fused_mixed and self.mixed_fuse_classifier and self.half and self.fuse_dwpw and cin % 64 == 0 and w2.shape[0] == 256
+                    and self.num_classes <= 32 and x.lo is not None):
+                pc = "decoder.refine_layers.%d" % (k + 1)
+                wc, bc = fold_bn(st, pc + ".conv.weight", None)
+                self.out_h, self.out_w = ohw
+                Mo = ohw[0] * ohw[1]
+                self.logits_buf = torch.zeros((_round_up(Mo, self.ROW_PAD), self.num_classes), dtype=torch.float32, device=dev)
+                self.labels_buf = torch.zeros(_round_up(Mo, self.ROW_PAD), dtype=torch.uint8, device=dev)
+                self._keep += [self.logits_buf, self.labels_buf]
+                self._dwpw(p + "+classifier", x, hw, cin, w, b, w2, b2, None, 0, 1, padding=0,
+                           classifier=(wc.reshape(self.num_classes, w2.shape[0]), bc, self.logits_buf, self.labels_buf))
+                self._release(x)
+                return
             y = self._act(ohw[0] * ohw[1], w2.shape[0], split=self.mixed)
             # "mixed": the decoder keeps every activation as hi + lo (the logits are most sensitive to roundings here:
             # tools/precision_study.py).  fuse_decoder (default): one k_dwpw_xs launch per block -- split input, depthwise weights as
