@@ -91,7 +91,7 @@ def test_full_split_logits_on_the_seeded_weights(hw, cuda_device):
     net = SegNet(fs.state_dict(0), h, w, precision="mixed", device=cuda_device, full_split=True)
     # no FP4 anywhere (w_split 2 of the fused depthwise op means "exact depthwise stage", out_mx of the fp32 classifier is the label map)
     assert not any(((op.w_split == 2 or op.out_mx) and not op.out_f32) or op.in_mx for op in net.ops)
-    assert all(op.in_lo and op.out_lo and op.w_split == 3 for op in net.ops if op.kind == OP_DWPW) and sum(op.kind == OP_DWPW for op in net.ops) == 5
+    assert all(op.in_lo and (op.out_lo or op.out_f32) and op.w_split == 3 for op in net.ops if op.kind == OP_DWPW) and sum(op.kind == OP_DWPW for op in net.ops) == 5
     assert all(op.out_lo for n, op in zip(net.op_names, net.ops) if op.kind in (1, 2, 3, 4, 5, 6) and not op.out_f32), \
         [n for n, op in zip(net.op_names, net.ops) if op.kind in (1, 2, 3, 4, 5, 6) and not op.out_f32 and not op.out_lo]
     net.forward(torch.from_numpy(fs.image_for(3, h, w)).to(cuda_device))
