@@ -354,6 +354,63 @@ def test_fused_depthwise_pointwise_with_the_classifier_in_its_epilogue(case, cud
     assert torch.all(labels[M:] == 99) and torch.all(logits[M:] == -7.0)
 
 
+@pytest.mark.parametrize("cls", [0, 1])
+def test_split_input_fused_depthwise_kernel_repeats_under_load(cls, cuda_device):
+    """Race screen for k_dwpw_xs (weights and depthwise parameters by inline-asm LDS-DMA, awaited with hand-counted `s_waitcnt vmcnt(18)` next to
+    the compiler's own waits for the tap loads; with cls the classifier epilogue re-uses the weight ring and the tiles as its staging area): a
+    decoder-sized launch (several tiles per CU), back to back with copies in between, must give the same bytes every time."""
+    import torch
+    from vision_semantic_segmentation_amd import _lib
+    from vision_semantic_segmentation_amd.network import OP_DWPW, AvlSegOp, dwpw_block_order, pack_dw_f32, pack_split_rows, split_f16
+    H, W, K, N, ncls = 200, 330, 256, 256, 19
+    OH, OW = H - 2, W - 2
+    M, Mi = OH * OW, H * W
+    Mp, Mip = (M + 255) // 256 * 256, (Mi + 255) // 256 * 256
+    g = torch.Generator().manual_seed(21)
+    x = torch.zeros((2, Mip, K), dtype=torch.float16)
+    x[0, :Mi] = torch.randn((Mi, K), generator=g).to(torch.float16)
+    x[1, :Mi] = (torch.randn((Mi, K), generator=g) * 2.0 ** -12).to(torch.float16)
+    w1, b1 = torch.randn((K, 1, 3, 3), generator=g).double() * 0.3, torch.randn(K, generator=g).double() * 0.1
+    w2 = torch.randn((N, K), generator=g, dtype=torch.float64) / K ** 0.5
+    xd, w2d, b2d = x.to(cuda_device), pack_split_rows(w2, 2).to(cuda_device), torch.randn(N, generator=g).to(cuda_device)
+    params = torch.cat([pack_dw_f32(w1, b1), dwpw_block_order(OH, OW)]).to(cuda_device)
+    op = AvlSegOp()
+    op.kind, op.dtype = OP_DWPW, _lib.AVL_F16
+    op.in_, op.in_lo, op.in2, op.weight, op.bias = xd[0].data_ptr(), xd[1].data_ptr(), params.data_ptr(), w2d.data_ptr(), b2d.data_ptr()
+    op.in_h, op.in_w, op.in_c, op.in_ld, op.in_rows = H, W, K, K, Mip
+    op.out_h, op.out_w, op.out_c, op.out_rows = OH, OW, N, Mp
+    op.relu, op.w_rows, op.ksize, op.stride, op.pad, op.dil, op.groups, op.w_split, op.w_layout = 1, 256, 3, 1, 0, 1, K, 3, 1
+    if cls:
+        wc32 = torch.zeros((32, N), dtype=torch.float64)
+        wc32[:ncls] = torch.randn((ncls, N), generator=g, dtype=torch.float64) / N ** 0.5
+        wcd, bcd = torch.stack(split_f16(wc32)).to(cuda_device), torch.zeros(32, device=cuda_device)
+        out = torch.zeros((Mp, ncls), dtype=torch.float32, device=cuda_device)
+        labels = torch.zeros(Mp, dtype=torch.uint8, device=cuda_device)
+        op.in2_lo, op.in3, op.in3_c, op.out, op.out_mx, op.out_f32, op.out_ld = bcd.data_ptr(), wcd.data_ptr(), ncls, out.data_ptr(), labels.data_ptr(), 1, ncls
+    else:
+        out = torch.zeros((2, Mp, N), dtype=torch.float16, device=cuda_device)
+        op.out, op.out_lo, op.out_ld = out[0].data_ptr(), out[1].data_ptr(), N
+    plan = C.c_void_p()
+    _lib.check(_lib.lib().avl_seg_plan_create((AvlSegOp * 1)(op), 1, C.byref(plan)), "avl_seg_plan_create")
+    try:
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.lib().avl_seg_plan_run(plan, s), "avl_seg_plan_run")
+        torch.cuda.synchronize()
+        ref = out.clone()
+        assert bool(torch.isfinite(ref.float()).all()) and float(ref.float().abs().max()) > 0
+        copies = [torch.zeros_like(out) for _ in range(4)]
+        bad = 0
+        for i in range(120):
+            _lib.lib().avl_seg_plan_run(plan, s)
+            copies[i % 4].copy_(out)
+            if i % 4 == 3:
+                torch.cuda.synchronize()
+                bad += sum(0 if torch.equal(c, ref) else 1 for c in copies)
+        assert bad == 0, "%d of 120 launches differ from the first" % bad
+    finally:
+        _lib.lib().avl_seg_plan_destroy(plan)
+
+
 @pytest.mark.parametrize("case", [(37, 53, 64, 1, 0), (20, 31, 512, 1, 0), (9, 9, 64, 2, 2)])
 def test_split_depthwise_and_bilinear(case, cuda_device):
     import torch

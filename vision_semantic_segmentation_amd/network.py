@@ -1175,7 +1175,7 @@ class SegNet(object):
         """float32 CPU tensor [out_h * out_w, out_c] of what op i wrote (hi + lo planes) -- valid right after a run of ops 0 .. i only (later ops
         recycle the buffers): diagnostics and tests (tools/layer_error_trace.py)."""
         op = self.ops[i]
-        rows, cols = op.out_h * op.out_w, op.out_c
+        rows, cols = op.out_h * op.out_w, (op.in3_c if (op.kind == OP_DWPW and op.out_f32) else op.out_c)     # (the fused classifier writes in3_c logits per pixel)
         dt = torch.float32 if (op.out_f32 or op.dtype == _lib.AVL_F32) else self.act_dtype
 
         def plane(ptr):
