@@ -294,7 +294,8 @@ def test_fused_depthwise_pointwise_with_the_classifier_in_its_epilogue(case, cud
     """round 5: AVL_OP_DWPW with out_f32 (k_dwpw_xs<CLS>): the decoder's last refine block (decoder.py:38-41), the classifier (decoder.py:42-43:
     1x1 conv with bias, no BN / ReLU) and torch.argmax (semantic_segmentation.py:56) in ONE launch -- the block's 256-channel result exists only
     in LDS, as f16 hi + lo tiles.  Logits against a float64 evaluation of the same operands; labels = the arg-max of the logits the kernel wrote,
-    first maximal index on ties (classes 1 and 3 get identical weights and win everywhere they can)."""
+    first maximal index on ties (classes 1 and 3 get identical weights and win everywhere they can); with five classes every logit is negative, so
+    a lane that holds no real class (classes 8 .., 12 ..) would win with its padding zeros if it took part."""
     import torch
     import torch.nn.functional as F
     from test_gpu_ops import _nhwc_rows
@@ -315,6 +316,8 @@ def test_fused_depthwise_pointwise_with_the_classifier_in_its_epilogue(case, cud
     if ncls > 3:
         wc[3], bc[3] = wc[1], bc[1]
         bc[1] = bc[3] = 3.0                       # the tied pair is the maximum on most pixels
+    if ncls == 5:
+        bc -= 9.0                                 # every real logit negative: the zero rows that pad the weights to 32 classes must not win
     M = OH * OW
     Mp = (M + 255) // 256 * 256
     src = torch.stack([_nhwc_rows(xh), _nhwc_rows(xl)]).to(cuda_device)

@@ -78,6 +78,27 @@ def test_image_sizes_that_are_no_multiple_of_anything(state, hw, cuda_device):
         assert np.array_equal(net.labels.cpu().numpy(), got.argmax(0).numpy())
 
 
+@pytest.mark.parametrize("ncls", [5, 33])
+def test_class_counts_other_than_19(ncls, cuda_device):
+    """MODEL.NUM_CLASSES is a configuration value of the reference (base_cfg.py:110).  Up to 32 classes the classifier and the arg-max ride in the
+    last refine block's epilogue (mixed) or in the classifier GEMM's (other precisions) -- at five classes half of the lanes that share a pixel hold
+    no real class and must not vote --; from 33 on: classifier GEMM + the stand-alone arg-max (more counts: tools/micro/num_classes.py)."""
+    import torch
+    from oracle import network_oracle as no
+    from vision_semantic_segmentation_amd.network import OP_ARGMAX, SegNet, random_state_dict
+    h, w = 96, 128
+    st = random_state_dict(0, num_classes=ncls)
+    img = np.random.default_rng(4).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    ref = no.forward_logits(st, img)[0]
+    for precision, bar in (("mixed", 1e-3), ("f16", 4e-3)):
+        net = SegNet(st, h, w, precision=precision, device=cuda_device, num_classes=ncls)
+        assert any(op.kind == OP_ARGMAX for op in net.ops) == (ncls > 32)
+        net.forward(torch.from_numpy(img).to(cuda_device))
+        got = net.logits.permute(2, 0, 1).float().cpu()
+        assert got.shape == ref.shape and float((got - ref).abs().max() / ref.abs().max()) <= bar
+        assert np.array_equal(net.labels.cpu().numpy(), got.argmax(0).numpy())
+
+
 @pytest.mark.parametrize("precision,bar", [("f32", 1e-4), ("mixed", 1e-3), ("split16", 1e-4)])
 def test_output_stride_16(state, precision, bar, cuda_device):
     """MODEL.OUTPUT_STRIDE = 16 (deeplab_v3_plus.py:30-36: ASPP dilations 1, 6, 12, 18; backbone/build.py:11-16: only layer4 trades its stride

@@ -835,8 +835,10 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
                 m = mt * TM + ml;
             }
         }
-        float best = a2[0][0];
-        int bi = 4 * ekq;
+        // (a lane whose classes 4 kq .. and 16 + 4 kq .. all lie beyond ncls -- kq >= 2 at five classes -- takes no part: index kNone)
+        constexpr int kNone = 1 << 20;
+        float best = 0.f;
+        int bi = kNone;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -845,7 +847,7 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
                 const float v = a2[t2][r];
                 if (cls < p.ncls) {
                     if (m < p.M) p.LG[(long long)m * p.ncls + cls] = v;
-                    if ((t2 | r) && (v > best || (v != v && best == best))) { best = v; bi = cls; }
+                    if (bi == kNone || v > best || (v != v && best == best)) { best = v; bi = cls; }
                 }
             }
 #pragma unroll
@@ -853,8 +855,8 @@ __global__ void __launch_bounds__(512) k_dwpw_xs(DwPwArgs p) {
             const float ov = __shfl_xor(best, sh, 64);
             const int oi = __shfl_xor(bi, sh, 64);
             const bool onan = ov != ov, bnan = best != best;
-            const bool take = onan ? (!bnan || oi < bi) : (!bnan && (ov > best || (ov == best && oi < bi)));
-            if (take) { best = ov; bi = oi; }
+            const bool better = onan ? (!bnan || oi < bi) : (!bnan && (ov > best || (ov == best && oi < bi)));
+            if (oi != kNone && (bi == kNone || better)) { best = ov; bi = oi; }
         }
         if (ekq == 0 && m < p.M) p.labels[m] = (unsigned char)bi;
         return;
