@@ -78,6 +78,27 @@ def test_image_sizes_that_are_no_multiple_of_anything(state, hw, cuda_device):
         assert np.array_equal(net.labels.cpu().numpy(), got.argmax(0).numpy())
 
 
+def test_low_level_branch_of_48_channels(cuda_device):
+    """MODEL.DECODER.LOW_LEVEL_OUT_CHANNELS is 256 in the reference's base_cfg.py:104 and 48 in the DeepLabV3+ paper: any width runs -- the
+    branch is padded with zero channels to the kernels' granule at plan-build time (zero conv rows, zero depthwise taps, zero pointwise
+    columns), which changes no value (more: tools/micro/option_matrix.py, profiles/r05/option_matrix.log)."""
+    import torch
+    from oracle import network_oracle as no
+    from vision_semantic_segmentation_amd.network import SegNet, random_state_dict
+    h, w = 96, 128
+    st = random_state_dict(0, low_level_out=48)
+    assert st["decoder.low_level_conv.conv.weight"].shape[0] == 48 and st["decoder.refine_layers.0.depthwise_cnn.conv.weight"].shape[0] == 304
+    img = np.random.default_rng(4).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    ref = no.forward_logits(st, img)[0]
+    for precision, bar in (("f32", 1e-5), ("mixed", 1e-3), ("f16", 4e-3)):
+        net = SegNet(st, h, w, precision=precision, device=cuda_device)
+        net.forward(torch.from_numpy(img).to(cuda_device))
+        got = net.logits.permute(2, 0, 1).float().cpu()
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert got.shape == ref.shape and err <= bar, (precision, err)
+        assert np.array_equal(net.labels.cpu().numpy(), got.argmax(0).numpy())
+
+
 @pytest.mark.parametrize("ncls", [5, 33])
 def test_class_counts_other_than_19(ncls, cuda_device):
     """MODEL.NUM_CLASSES is a configuration value of the reference (base_cfg.py:110).  Up to 32 classes the classifier and the arg-max ride in the

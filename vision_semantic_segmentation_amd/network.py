@@ -1050,7 +1050,14 @@ class SegNet(object):
         """decoder (decoder.py:45-51) -> logits_buf / labels_buf"""
         dev = self.device
         w, b = fold_bn(st, "decoder.low_level_conv.conv.weight", "decoder.low_level_conv.bn")
-        low_out = w.shape[0]
+        # MODEL.DECODER.LOW_LEVEL_OUT_CHANNELS other than the reference's 256 (48 in the DeepLabV3+ paper): the low-level branch is padded with
+        # zero channels to the kernels' granule (zero rows of this conv, zero depthwise taps and zero pointwise columns in the first refine
+        # block): ReLU(0) = 0 contributes exactly nothing
+        low_true = w.shape[0]
+        low_out = _round_up(low_true, 128 if self.mixed else 64)
+        if low_out != low_true:
+            w = torch.cat([w, torch.zeros((low_out - low_true,) + tuple(w.shape[1:]), dtype=w.dtype)])
+            b = torch.cat([b, torch.zeros(low_out - low_true, dtype=b.dtype)])
         Ml = low_hw[0] * low_hw[1]
         cat2 = self._act(Ml, aspp_out + low_out, split=self.mixed)
         self._gemm("decoder.low_level_conv", low, low_hw, low_c, w, b, cat2, dst_col=aspp_out)
@@ -1064,6 +1071,11 @@ class SegNet(object):
             ohw = (hw[0] - 2, hw[1] - 2)                                # padding 0 (decoder.py:33-36 default)
             w, b = fold_bn(st, p + ".depthwise_cnn.conv.weight", p + ".depthwise_cnn.bn")
             w2, b2 = fold_bn(st, p + ".pointwise_cnn.conv.weight", p + ".pointwise_cnn.bn")
+            if k == 0 and w.shape[0] != cin:             # the padded low-level channels (see above)
+                npad = cin - w.shape[0]
+                w = torch.cat([w, torch.zeros((npad,) + tuple(w.shape[1:]), dtype=w.dtype)])
+                b = torch.cat([b, torch.zeros(npad, dtype=b.dtype)])
+                w2 = torch.cat([w2, torch.zeros((w2.shape[0], npad) + tuple(w2.shape[2:]), dtype=w2.dtype)], dim=1)
             last = ("decoder.refine_layers.%d.depthwise_cnn.conv.weight" % (k + 1)) not in st
             fused_mixed = self.mixed and self.mixed_fuse_decoder and self.mixed_dw_exact
             # the last refine block also carries the classifier (decoder.py:42-43) and the arg-max in its epilogue: its 256-channel result never goes to memory
